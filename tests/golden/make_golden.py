@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REFERENCE's own Python modules (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.pt
+
+Needs /root/reference (absent on the GPU box: the committed *.pt files are what travels).  The reference is
+imported, never copied.  Missing third-party packages are satisfied by oracle/_stubs (see its README for
+what that means for parity pinning).  All inputs are regenerated from seeds by oracle/synth_inputs.py and
+oracle/unet_ref.synth_state_dict, so only OUTPUTS (and a few tiny inputs) are stored.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = os.environ.get("UNIVST_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def plant_environment():
+    import transformers  # noqa: F401  (must be imported BEFORE the empty torchvision stub is planted)
+    from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "_stubs"))
+    sys.path.insert(0, REF)
+    sys.path.insert(0, ROOT)
+    from PIL import Image
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def imwrite(path, arr):
+        Image.fromarray(np.asarray(arr)).save(path)
+
+    mod("imageio", imwrite=imwrite, imsave=imwrite)
+    d = mod("decord")
+    d.bridge = types.SimpleNamespace(set_bridge=lambda *_: None)
+    mod("requests")
+    mod("cv2")
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms")
+    tv.utils = mod("torchvision.utils")
+    tv.models = mod("torchvision.models")
+    tv.models.optical_flow = mod("torchvision.models.optical_flow", raft_large=None, Raft_Large_Weights=None)
+    torch.cuda.get_device_name = lambda *a, **k: "cpu"
+    # reference hard-codes .cuda()/.to("cuda") in mask_propagation.py:104,138 — redirect to CPU
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    _to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        return _to(self, *a, **k)
+
+    torch.Tensor.to = to
+
+
+def build_reference_unet(cfg, sd):
+    from backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel
+    kw = {k: cfg[k] for k in ("in_channels", "out_channels", "block_out_channels", "layers_per_block",
+                              "cross_attention_dim", "attention_head_dim", "norm_num_groups", "norm_eps")}
+    unet = UNetPseudo3DConditionModel(sample_size=64, **kw)   # SD-v1.5 config.json has sample_size 64
+    missing = set(unet.state_dict().keys()) ^ set(sd.keys())
+    assert not missing, f"state-dict key mismatch: {sorted(missing)[:5]}"
+    unet.load_state_dict(sd)
+    return unet.eval()
+
+
+class FakeTokenizer:
+    model_max_length = 77
+
+    def __call__(self, prompt, **kw):
+        n = len(prompt) if isinstance(prompt, list) else 1
+        return types.SimpleNamespace(input_ids=torch.zeros(n, 77, dtype=torch.long), attention_mask=None)
+
+    def batch_decode(self, ids):
+        return [""]
+
+
+class FakeTextEncoder(torch.nn.Module):
+    def __init__(self, emb):
+        super().__init__()
+        self.emb = torch.nn.Parameter(emb, requires_grad=False)
+        self.config = types.SimpleNamespace()
+
+    def forward(self, ids, attention_mask=None):
+        return (self.emb.expand(ids.shape[0], -1, -1),)
+
+
+class FakeVAE(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.p = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.config = types.SimpleNamespace(block_out_channels=(1, 1, 1, 1), scaling_factor=0.18215)
+
+    def forward(self, x, num_frames=1):
+        return x
+
+    def decode(self, z, num_frames=1):
+        return types.SimpleNamespace(sample=torch.zeros(z.shape[0], 3, z.shape[2] * 8, z.shape[3] * 8))
+
+
+@torch.no_grad()
+def main():
+    plant_environment()
+    from oracle import unet_ref, pipeline_ref, maskprop_ref, flow_ref, synth_inputs as si
+    from backbones.video_diffusion_sd import pnp_utils as ref_pnp
+    gold = {}
+    report = []
+
+    def chk(name, ref, mine, tol=1e-4):
+        err = (ref.double() - mine.double()).abs().max().item()
+        scale = ref.double().abs().max().item() + 1e-12
+        report.append((name, err, err / scale))
+        assert err / scale < tol, f"oracle disagrees with reference on {name}: {err} (rel {err / scale})"
+
+    # ---- G1: AdaINs (pnp_utils.py:114-139)
+    g = torch.Generator().manual_seed(101)
+    cnt, sty = torch.randn(4, 32, 16, generator=g), 0.5 + 2 * torch.randn(4, 32, 16, generator=g)
+    gold["g1_attention_adain"] = dict(cnt=cnt, sty=sty, out=ref_pnp.attention_adain(cnt, sty))
+    chk("attention_adain", gold["g1_attention_adain"]["out"], unet_ref.attention_adain(cnt, sty))
+    lc, ls = torch.randn(1, 4, 4, 8, 8, generator=g), 0.3 + 1.5 * torch.randn(1, 4, 4, 8, 8, generator=g)
+    gold["g1_latent_adain"] = dict(cnt=lc, sty=ls, out=ref_pnp.latent_adain(lc, ls))
+    chk("latent_adain", gold["g1_latent_adain"]["out"], unet_ref.latent_adain(lc, ls))
+
+    # ---- G5: tiny UNet, three branches, PnP registered, idx in {0, 25, 26}; + feature dump; + no-PnP B=1
+    cfg = unet_ref.TINY_CONFIG
+    F_, h_, w_ = 4, 16, 16
+    text = si.text_embedding(cfg["cross_attention_dim"])
+    for tag, trivial in (("trivial", True), ("general", False)):
+        sd = unet_ref.synth_state_dict(cfg, seed=33, trivial_temporal=trivial)
+        unet = build_reference_unet(cfg, sd)
+        pipe = types.SimpleNamespace(unet=unet)
+        x = torch.cat([si.content_latent(50, F_, h_, w_), si.style_latent(50, F_, h_, w_),
+                       si.content_latent(49, F_, h_, w_)])
+        ctx = text.expand(3, -1, -1).contiguous()
+        # single-branch call before PnP registration, with feature dump (inversion path)
+        with tempfile.TemporaryDirectory() as td:
+            eps1 = unet(x[:1], 301, encoder_hidden_states=ctx[:1], ft_indices=[2], ft_timesteps=[301],
+                        ft_path=td).sample
+            feat = torch.load(os.path.join(td, "inversion_feature_map_2_block_301_step.pt"))
+        o_eps1, o_feats = unet_ref.unet_forward(sd, cfg, x[:1], 301, ctx[:1], None, ft_indices=[2],
+                                                exact_temporal=True)
+        chk(f"unet_{tag}_single", eps1, o_eps1)
+        chk(f"unet_{tag}_feat", feat, o_feats[2])
+        gold[f"g5_{tag}_single"] = dict(eps=eps1, feat=feat.half() if trivial else None)
+        ref_pnp.register_spatial_attention_pnp(pipe)
+        for idx, t in ((0, 981), (25, 481), (26, 461)):
+            ref_pnp.register_time(pipe, idx)
+            eps = unet(x, t, encoder_hidden_states=ctx).sample
+            o_eps, _ = unet_ref.unet_forward(sd, cfg, x, t, ctx, pnp_idx=idx, exact_temporal=True)
+            chk(f"unet_{tag}_pnp{idx}", eps, o_eps)
+            if trivial:   # the fast path the product also takes must equal the exact one
+                o_fast, _ = unet_ref.unet_forward(sd, cfg, x, t, ctx, pnp_idx=idx, exact_temporal=False)
+                chk(f"unet_{tag}_pnp{idx}_fast", eps, o_fast)
+            gold[f"g5_{tag}_pnp{idx}"] = dict(t=t, eps=eps)
+
+    # ---- G7: next_step (ddim_inversion.py:190-204) + restated DDIMScheduler.step over all 50 timesteps
+    from diffusers import DDIMScheduler
+    from inversion_tools.ddim_inversion import next_step
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    osch = pipeline_ref.DDIMSchedule()
+    osch.set_timesteps(50)
+    assert torch.equal(sch.timesteps, osch.timesteps)
+    z, e = torch.randn(1, 4, 2, 8, 8, generator=g), torch.randn(1, 4, 2, 8, 8, generator=g)
+    ns, st = [], []
+    for t in sch.timesteps:
+        ns.append(next_step(e, int(t), z, sch))
+        st.append(sch.step(e, int(t), z).prev_sample)
+        chk(f"next_step_{int(t)}", ns[-1], osch.next_step(e, t, z), 1e-6)
+        chk(f"step_{int(t)}", st[-1], osch.step(e, t, z)[0], 1e-6)
+    gold["g7_ddim"] = dict(z=z, e=e, next=torch.stack(ns), prev=torch.stack(st), timesteps=sch.timesteps.clone())
+
+    # ---- G8: mask propagation (src/mask_propagation.py), full video_mask_propogation via files
+    import src.mask_propagation as ref_mp
+    from PIL import Image
+    feats = si.maskprop_features()
+    first = si.soft_first_mask()
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as td:
+        fp = os.path.join(td, "feat.pt")
+        torch.save(feats, fp)
+        mp = os.path.join(td, "first.png")
+        Image.fromarray(first).save(mp)
+        args = types.SimpleNamespace(temperature=0.2, n_last_frames=9, topk=15, sample_ratio=0.3, num_frames=16,
+                                     mask_path=mp, backbone="sd", feature_path=fp, output_path=td)
+        os.chdir(REF)
+        torch.manual_seed(33)
+        ref_mp.video_mask_propogation(args)
+        os.chdir(cwd)
+        ref_masks = np.stack([np.array(Image.open(os.path.join(td, "sd", "first", "%05d.png" % i)))
+                              for i in range(16)])
+    torch.manual_seed(33)
+    mine = np.stack(maskprop_ref.video_mask_propagation(feats, first))
+    assert np.array_equal(ref_masks, mine), "mask-propagation oracle is not bit-exact vs the reference"
+    report.append(("maskprop_bit_exact", 0.0, 0.0))
+    gold["g8_maskprop"] = dict(masks=torch.from_numpy(np.packbits(ref_masks > 0, axis=-1)),
+                               frame0=torch.from_numpy(ref_masks[0]))
+
+    # ---- G9: occlusion / apply_mask (src/cal_optica_flow.py:20-29,43-46)
+    import src.cal_optica_flow as ref_fl
+    H = W = 64
+    fwd = si.translation_flow(H, W, 4.0, -2.0, 1)
+    bwd = si.translation_flow(H, W, -4.0, 2.0, 2)
+    bwd[10:20, 10:30] += 3.0
+    occ = ref_fl.compute_occlusion_mask(fwd, bwd, threshold=1.5)
+    assert np.array_equal(occ, flow_ref.compute_occlusion_mask(fwd, bwd, threshold=1.5))
+    rs = np.random.RandomState(5)
+    img, orig = rs.randint(0, 256, (H, W, 3)).astype(np.uint8), rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    am = ref_fl.apply_mask(img, occ, orig)
+    assert np.array_equal(am, flow_ref.apply_mask(img, occ, orig))
+    gold["g9_flow"] = dict(occ=torch.from_numpy(occ), applied=torch.from_numpy(am))
+    report.append(("occlusion/apply_mask_bit_exact", 0.0, 0.0))
+
+    # ---- G10: the reference's own video_style_transfer loop through the stubs (tiny UNet, F=16, 50 steps)
+    from backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
+    import backbones.video_diffusion_sd.pipelines.stable_diffusion as ref_pipe_mod
+    sd = unet_ref.synth_state_dict(cfg, seed=33, trivial_temporal=True)
+    F_, h_, w_ = 16, 16, 16
+    keep = (0, 25, 26, 40, 41, 45, 46, 49)
+    masks = si.disc_masks(F_, h_ * 8, w_ * 8)
+    for tag, use_mask in (("nomask", False), ("mask", True)):
+        unet = build_reference_unet(cfg, sd)
+        pipe = SpatioTemporalStableDiffusionPipeline(vae=FakeVAE(), text_encoder=FakeTextEncoder(text),
+                                                     tokenizer=FakeTokenizer(), unet=unet,
+                                                     scheduler=DDIMScheduler())
+        with tempfile.TemporaryDirectory() as td:
+            cdir, sdir, mdir = (os.path.join(td, n) for n in ("c", "s", "m"))
+            for d in (cdir, sdir, mdir):
+                os.makedirs(d)
+            for k in range(51):
+                torch.save(si.content_latent(k, F_, h_, w_), os.path.join(cdir, f"ddim_latents_{k}.pt"))
+                torch.save(si.style_latent(k, F_, h_, w_), os.path.join(sdir, f"ddim_latents_{k}.pt"))
+            for f in range(F_):
+                Image.fromarray(masks[f]).save(os.path.join(mdir, "%05d.png" % f))
+            lat0 = ref_pnp.latent_adain(si.content_latent(50, F_, h_, w_), si.style_latent(50, F_, h_, w_))
+            ref_pnp.register_spatial_attention_pnp(pipe)
+            cap = {}
+            pipe.video_style_transfer("", latents=lat0, num_inference_steps=50, content_inv_path=cdir,
+                                      style_inv_path=sdir, mask_path=mdir if use_mask else None,
+                                      callback=lambda i, t, l: cap.__setitem__(i, l.clone()) if i in keep else None)
+            ref_mask = ref_pipe_mod.load_mask(mdir) if use_mask else None
+        # oracle loop on the same inputs
+        osch = pipeline_ref.DDIMSchedule()
+        mine = {}
+        ctx = text.expand(3, -1, -1).contiguous()
+        fn = lambda x, t, i: unet_ref.unet_forward(sd, cfg, x, int(t), ctx, pnp_idx=i, exact_temporal=False)[0]
+        ci = [si.content_latent(k, F_, h_, w_) for k in range(51)]
+        sy = [si.style_latent(k, F_, h_, w_) for k in range(51)]
+        m01 = torch.from_numpy(pipeline_ref.mask_from_png_values(masks))[None] if use_mask else None
+        if use_mask:
+            assert torch.equal(ref_mask, m01)
+        pipeline_ref.video_style_transfer_loop(
+            fn, osch, unet_ref.latent_adain(ci[50], sy[50]), ci, sy, m01, 50,
+            callback=lambda i, t, l: mine.__setitem__(i, l.clone()) if i in keep else None)
+        for i in keep:
+            chk(f"transfer_{tag}_i{i}", cap[i], mine[i], 2e-3)
+        gold[f"g10_{tag}"] = {f"i{i}": cap[i] for i in keep}
+
+    for k, v in gold.items():
+        torch.save(v, os.path.join(OUT, k + ".pt"))
+    with open(os.path.join(OUT, "REPORT.txt"), "w") as f:
+        f.write("oracle vs reference (max abs err, rel to max|ref|) — generated by make_golden.py\n")
+        for name, e, r in report:
+            f.write(f"{name:40s} {e:.3e} {r:.3e}\n")
+    print(open(os.path.join(OUT, "REPORT.txt")).read())
+
+
+if __name__ == "__main__":
+    main()

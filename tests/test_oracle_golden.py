@@ -1,0 +1,109 @@
+"""CPU: the oracle (oracle/*.py) against the golden vectors produced by the reference's own modules
+(tests/golden/make_golden.py).  fp32; tolerance 1e-4 relative to max|ref| (observed <= 1.1e-6)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_ref, pipeline_ref, maskprop_ref, flow_ref, synth_inputs as si
+
+TOL = 1e-4
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12)).item()
+
+
+def test_adains(golden):
+    g = golden("g1_attention_adain")
+    assert rel(unet_ref.attention_adain(g["cnt"], g["sty"]), g["out"]) < TOL
+    g = golden("g1_latent_adain")
+    assert rel(unet_ref.latent_adain(g["cnt"], g["sty"]), g["out"]) < TOL
+
+
+@pytest.mark.parametrize("tag,trivial", [("trivial", True), ("general", False)])
+def test_tiny_unet(golden, tag, trivial):
+    cfg = unet_ref.TINY_CONFIG
+    sd = unet_ref.synth_state_dict(cfg, seed=33, trivial_temporal=trivial)
+    F_, h_, w_ = 4, 16, 16
+    x = torch.cat([si.content_latent(50, F_, h_, w_), si.style_latent(50, F_, h_, w_),
+                   si.content_latent(49, F_, h_, w_)])
+    ctx = si.text_embedding(cfg["cross_attention_dim"]).expand(3, -1, -1).contiguous()
+    g = golden(f"g5_{tag}_single")
+    eps, feats = unet_ref.unet_forward(sd, cfg, x[:1], 301, ctx[:1], None, ft_indices=[2])
+    assert rel(eps, g["eps"]) < TOL
+    if g["feat"] is not None:
+        assert rel(feats[2], g["feat"].float()) < 2e-3      # stored as fp16
+    for idx in (0, 25, 26):
+        g = golden(f"g5_{tag}_pnp{idx}")
+        eps, _ = unet_ref.unet_forward(sd, cfg, x, g["t"], ctx, pnp_idx=idx, exact_temporal=not trivial)
+        assert rel(eps, g["eps"]) < TOL
+
+
+def test_ddim(golden):
+    g = golden("g7_ddim")
+    s = pipeline_ref.DDIMSchedule()
+    s.set_timesteps(50)
+    assert torch.equal(s.timesteps, g["timesteps"])
+    for k, t in enumerate(s.timesteps):
+        assert rel(s.next_step(g["e"], t, g["z"]), g["next"][k]) < 1e-6
+        assert rel(s.step(g["e"], t, g["z"])[0], g["prev"][k]) < 1e-6
+
+
+def test_maskprop_bit_exact(golden):
+    g = golden("g8_maskprop")
+    torch.manual_seed(33)
+    masks = np.stack(maskprop_ref.video_mask_propagation(si.maskprop_features(), si.soft_first_mask()))
+    ref = np.unpackbits(g["masks"].numpy(), axis=-1).astype(bool)
+    assert np.array_equal(masks[0], g["frame0"].numpy())
+    assert np.array_equal(masks[1:] > 0, ref[1:])
+    assert set(np.unique(masks[1:])) <= {0, 255}
+
+
+def test_flow_pieces(golden):
+    g = golden("g9_flow")
+    H = W = 64
+    fwd = si.translation_flow(H, W, 4.0, -2.0, 1)
+    bwd = si.translation_flow(H, W, -4.0, 2.0, 2)
+    bwd[10:20, 10:30] += 3.0
+    occ = flow_ref.compute_occlusion_mask(fwd, bwd, threshold=1.5)
+    assert np.array_equal(occ, g["occ"].numpy())
+    rs = np.random.RandomState(5)
+    img, orig = rs.randint(0, 256, (H, W, 3)).astype(np.uint8), rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    assert np.array_equal(flow_ref.apply_mask(img, occ, orig), g["applied"].numpy())
+
+
+def test_remap_identity_and_shift():
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (32, 48, 3)).astype(np.uint8)
+    gx, gy = np.meshgrid(np.arange(48), np.arange(32))
+    assert np.array_equal(flow_ref.remap_bilinear_u8(img, gx.astype(np.float32), gy.astype(np.float32)), img)
+    out = flow_ref.remap_bilinear_u8(img, gx.astype(np.float32) + 1, gy.astype(np.float32))
+    assert np.array_equal(out[:, :-1], img[:, 1:]) and (out[:, -1] == 0).all()
+    half = flow_ref.remap_bilinear_u8(img, gx.astype(np.float32) + 0.5, gy.astype(np.float32))
+    exp = (img[:, :-1].astype(np.int64) * 16384 + img[:, 1:].astype(np.int64) * 16384 + 16384) >> 15
+    assert np.array_equal(half[:, :-1], exp.astype(np.uint8))
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_transfer_loop(golden, tag):
+    """the reference's own 50-step three-branch loop (tiny UNet, F=16) vs the oracle loop; every branch of
+    the step logic is sampled: i in {0,25,26,40,41,45,46,49}."""
+    g = golden(f"g10_{tag}")
+    cfg = unet_ref.TINY_CONFIG
+    sd = unet_ref.synth_state_dict(cfg, seed=33)
+    F_, h_, w_ = 16, 16, 16
+    ctx = si.text_embedding(cfg["cross_attention_dim"]).expand(3, -1, -1).contiguous()
+    ci = [si.content_latent(k, F_, h_, w_) for k in range(51)]
+    sy = [si.style_latent(k, F_, h_, w_) for k in range(51)]
+    m01 = None
+    if tag == "mask":
+        m01 = torch.from_numpy(pipeline_ref.mask_from_png_values(si.disc_masks(F_, h_ * 8, w_ * 8)))[None]
+    got = {}
+    keep = (0, 25, 26, 40, 41, 45, 46, 49)
+    with torch.no_grad():
+        pipeline_ref.video_style_transfer_loop(
+            lambda x, t, i: unet_ref.unet_forward(sd, cfg, x, int(t), ctx, pnp_idx=i, exact_temporal=False)[0],
+            pipeline_ref.DDIMSchedule(), unet_ref.latent_adain(ci[50], sy[50]), ci, sy, m01, 50,
+            callback=lambda i, t, l: got.__setitem__(i, l.clone()) if i in keep else None)
+    for i in keep:
+        assert rel(got[i], g[f"i{i}"]) < 2e-3, i
