@@ -1,0 +1,150 @@
+/* univst.h — C ABI of libunivst_hip.so: the MI355X (gfx950) implementation of the UniVST SD-v1.5
+ * denoising hot path.  Plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers
+ * unless stated otherwise; all tensors are fp16 (IEEE binary16) unless stated otherwise; all work is
+ * enqueued on the caller-supplied hipStream_t (passed as void*) and the call returns without syncing.
+ *
+ * Every entry returns 0 on success or a negative code (UNIVST_ERR_*); the message is available through
+ * univst_last_error() (thread-local).  Handles are not re-entrant: one call at a time per handle.
+ *
+ * The reference (QuanjianSong/UniVST) is pure Python with no native layer, so there is no existing FFI to
+ * mimic; each entry names the reference interface (file:line under the reference checkout) it replaces.
+ * The Python binding a maintainer adds is univst_amd/_native.py (ctypes); see INTEGRATION.md.
+ */
+#ifndef UNIVST_H
+#define UNIVST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNIVST_OK 0
+#define UNIVST_ERR_ARG (-1)
+#define UNIVST_ERR_HIP (-2)
+#define UNIVST_ERR_UNSUPPORTED (-3)
+#define UNIVST_ERR_STATE (-4)
+
+#define UNIVST_F16 0
+#define UNIVST_F32 1
+
+const char* univst_last_error(void);
+int univst_abi_version(void);
+
+/* ------------------------------------------------------------------ UNet handle
+ * Replaces backbones/video_diffusion_sd/models/unet_3d_condition.py:49-230 (ctor), :306-443 (forward),
+ * :445-509 (from_2d_model / load_2d_state_dict). */
+typedef struct univst_unet univst_unet;
+
+typedef struct {
+    int in_channels, out_channels;
+    int block_out_channels[4];
+    int layers_per_block;
+    int cross_attention_dim;
+    int attention_heads;        /* SD config key attention_head_dim, used as HEAD COUNT (unet_3d_blocks.py:269-271) */
+    int norm_num_groups;
+    float norm_eps;
+    int flip_sin_to_cos;
+    float freq_shift;
+} univst_unet_cfg;
+
+/* PnP state = what register_spatial_attention_pnp / register_time (pnp_utils.py:7-111) poke into attn1. */
+typedef struct {
+    int registered;             /* 1: the 8 decoder attn1 layers use the PnP forward ([-1,'first'] K/V sources) */
+    int idx;                    /* step index (register_time) */
+    float eta1, eta2;           /* window: eta1 <= idx <= eta2*50 */
+    float alpha, gamma;         /* 0.65, 3.0 (pnp_utils.py:49-51) */
+} univst_pnp;
+
+int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out);
+int univst_unet_destroy(univst_unet* h);
+/* key = reference state-dict name (incl. *_temporal*); data is copied (D2D) and converted to fp16 */
+int univst_unet_load_tensor(univst_unet* h, const char* key, const void* dev_ptr, int dtype, const int64_t* shape,
+                            int ndim, void* stream);
+/* builds the derived weight layouts ([Cout][ky][kx][Cin] convs, fused QKV / KV, GEGLU-interleaved FF) and
+ * verifies that the *_temporal* layers are the identity/bias-only initialisation (else UNIVST_ERR_UNSUPPORTED) */
+int univst_unet_finalize(univst_unet* h, void* stream);
+/* (re)allocates the activation arena for this geometry; forward() calls it implicitly on first use */
+int univst_unet_reserve(univst_unet* h, int B, int F, int H, int W);
+/* sample [B,Cin,F,H,W], text [B,77,Dtxt] -> eps [B,Cout,F,H,W].  feat_out (may be NULL): receives the output
+ * of up_blocks[ft_index] for batch element 0 as [F,H',W',C] (unet_3d_condition.py:430-436). */
+int univst_unet_forward(univst_unet* h, const void* sample, float timestep, const void* text, int B, int F, int H,
+                        int W, int text_len, const univst_pnp* pnp, void* eps_out, void* feat_out, int ft_index,
+                        void* stream);
+/* frame-sharded multi-GPU: this rank holds frames [f0, f0+F) of a clip of Ftot frames per branch.
+ * comm callbacks are invoked on the host between launches (RCCL via torch.distributed on the Python side). */
+typedef int (*univst_allreduce_fn)(void* user, void* dev_f32, int count, void* stream);
+typedef int (*univst_kv_exchange_fn)(void* user, void* dev_kv_send_last, void* dev_kv_first_bcast, void* dev_kv_recv_prev,
+                                     void* dev_kv_recv_first, int64_t bytes_per_frame, void* stream);
+int univst_unet_set_comm(univst_unet* h, int rank, int world, univst_allreduce_fn ar, univst_kv_exchange_fn kv,
+                         void* user);
+
+/* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
+/* Y[M,N] = X[M,K] W[N,K]^T + bias + residual; geglu: W rows must be pre-interleaved, writes N/2 columns.
+ * Replaces torch Linear / 1x1 conv call sites attention.py:123,141,375-377,425. */
+int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr,
+                  void* Y, int64_t ldy, int M, int N, int K, int geglu, void* stream);
+/* NHWC implicit-GEMM conv: taps 9 (3x3, pad 1) or 1; optional second source (channel concat), fused nearest x2
+ * upsample of the input, stride 1/2.  W is [Cout][taps][C1+C2].  Replaces resnet.py:57-80,145,226. */
+int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, int stride,
+                     int taps, const void* W, const void* bias, const void* rowbias, int rows_per_rowbias,
+                     const void* residual, void* Y, int Cout, void* stream);
+/* GroupNorm(+SiLU) on NHWC rows; rows_per_stat = F*H*W (5-D, stats across frames: resnet.py:338,369) or H*W
+ * (per frame: attention.py:121).  workspace: univst_groupnorm_workspace_bytes(). */
+int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups);
+int univst_groupnorm_nhwc(const void* X1, const void* X2, int C1, int C2, int64_t rows, int rows_per_stat, int groups,
+                          float eps, const void* gamma, const void* beta, int silu, void* Y, void* workspace,
+                          void* stream);
+int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta, int64_t rows, int C, float eps,
+                     void* stream);
+/* multi-source flash attention.  q rows (bf*Nq+i) at ldq, k/v rows (src*Nkv+j) at ldkv, src_idx int32 [BF][nsrc].
+ * Replaces attention.py:384-420, pnp_utils.py:59-92 and diffusers AttnProcessor2_0. */
+int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
+                     const int32_t* src_idx, int nsrc, int BF, int Nq, int Nkv, int heads, int head_dim, void* stream);
+/* AdaIN-guided attention shift in place on the fused QKV buffer [3*F*N, 3C]; stats_ws: 4*F*2C floats.
+ * Replaces pnp_utils.py:47-57 + attention_adain :114-125. */
+int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, float alpha, float beta, float gamma,
+                                 void* stats_ws, void* stream);
+/* latent_adain on [1,C,F,H,W] (pnp_utils.py:128-139) */
+int univst_latent_adain(const void* cnt, const void* sty, void* out, int C, int F, int HW, void* stream);
+/* out = cx*x + ce*eps: DDIMScheduler.step / next_step with host-folded coefficients (stable_diffusion.py:761,
+ * ddim_inversion.py:190-204) */
+int univst_axpby(const void* x, const void* eps, void* out, float cx, float ce, int64_t n, void* stream);
+/* out = (1-m)*a + m*b, m [F,h,w] broadcast over C (stable_diffusion.py:687-702); m NULL => m = 0 */
+int univst_mask_blend(const void* a, const void* b, const void* m, void* out, int C, int64_t FHW, void* stream);
+/* uint8 {0,1} mask [F,H,W] -> fp16 [F,h,w], torch bilinear align_corners=False (stable_diffusion.py:689) */
+int univst_mask_resize(const uint8_t* mask, void* out, int F, int H, int W, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------ mask propagation (src/mask_propagation.py:72-83,60-69) */
+/* one target frame: feat_tar [hw,C] f32, feat_src [Nsrc,C] f32 (row-major, un-normalised), segs_src [ncls,Nsrc] f32
+ * -> segs_tar [ncls,hw] f32.  workspace: univst_maskprop_workspace_bytes(). */
+int64_t univst_maskprop_workspace_bytes(int hw, int Nsrc, int C);
+int univst_maskprop_frame(const float* feat_tar, const float* feat_src, const float* segs_src, float* segs_tar, int hw,
+                          int Nsrc, int C, int ncls, float temperature, int topk, void* workspace, void* stream);
+/* segs [ncls,h,w] f32 -> bilinear up to [H,W], per-class min-max, first-max argmax, !=0 -> 255 : uint8 [H,W] */
+int univst_maskprop_finalize(const float* segs, uint8_t* mask_out, int ncls, int h, int w, int H, int W, void* workspace,
+                             void* stream);
+
+/* ------------------------------------------------------------------ flow warp + occlusion + window blend
+ * (src/cal_optica_flow.py:20-46, stable_diffusion.py:731-751) */
+/* acc[H,W,3] f32 += get_warp(key, now): occlusion ||(c+fwd)+bwd-c|| > thr, cv2.remap-exact bilinear warp of `now`
+ * by fwd, occluded pixels take `key`.  key/now uint8 [H,W,3], fwd/bwd f32 [H,W,2]. */
+int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int H,
+                           int W, float threshold, void* stream);
+int univst_accumulate_u8(const uint8_t* frame, float* acc, int64_t n, void* stream);
+/* dst[i] = (uint8) trunc(acc[i] / weight) */
+int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ per-kernel-class HIP-event timing (bench.py roofline leg)
+ * classes: 0 linear GEMM, 1 implicit-GEMM conv, 2 attention, 3 groupnorm, 4 layernorm, 5 adain shift.
+ * While enabled every launch of these classes is bracketed by hipEvents on its stream; collect() waits for
+ * them and returns per class: summed ms, launch count, algorithmic flops and algorithmic bytes. */
+#define UNIVST_PROFILE_CLASSES 6
+int univst_profile_enable(int on);
+int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int nclasses);
+
+/* bring-up aid: what ds_read_b64_tr_b16 returns per lane for a known LDS image (256 floats) */
+int univst_debug_tr16(float* out256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -160,6 +160,22 @@ def main():
                 chk(f"unet_{tag}_pnp{idx}_fast", eps, o_fast)
             gold[f"g5_{tag}_pnp{idx}"] = dict(t=t, eps=eps)
 
+    # ---- G6: seeded init of the never-loaded *_temporal* parameters (construction-order pin; SURVEY "hard parts")
+    from src.util import seed_everything
+    from backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel as RefUNet
+    seed_everything(33)
+    kw = {k: cfg[k] for k in ("in_channels", "out_channels", "block_out_channels", "layers_per_block",
+                              "cross_attention_dim", "attention_head_dim", "norm_num_groups", "norm_eps")}
+    fresh = RefUNet(sample_size=64, **kw).state_dict()
+    g6 = {k: v.clone() for k, v in fresh.items() if k.endswith("attn_temporal.to_out.0.bias")}
+    for k in ("down_blocks.0.attentions.0.transformer_blocks.0.attn_temporal.to_q.weight",
+              "up_blocks.3.attentions.2.transformer_blocks.0.attn_temporal.to_v.weight",
+              "up_blocks.3.attentions.2.transformer_blocks.0.norm_temporal.weight",
+              "conv_out.conv_temporal.weight"):
+        g6[k] = fresh[k].clone()
+    gold["g6_temporal_init"] = g6
+    report.append((f"temporal_init_tensors={len(g6)}", 0.0, 0.0))
+
     # ---- G7: next_step (ddim_inversion.py:190-204) + restated DDIMScheduler.step over all 50 timesteps
     from diffusers import DDIMScheduler
     from inversion_tools.ddim_inversion import next_step

@@ -1,0 +1,70 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports exactly the symbols include/univst.h declares
+(and the ctypes binding knows every one of them).  No compute call is made here."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "univst.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(univst_[a-z0-9_]+)\s*\(", src)) - {"univst_allreduce_fn", "univst_kv_exchange_fn"}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from univst_amd import _native
+    if not os.path.exists(_native.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _native.load()
+
+
+def test_exports_match_header(lib):
+    from univst_amd import _native
+    syms = header_symbols()
+    assert syms, "no symbols parsed from include/univst.h"
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (univst_[a-z0-9_]+)", out))
+    assert syms == exported, f"header-only: {sorted(syms - exported)}  lib-only: {sorted(exported - syms)}"
+    assert syms == set(_native.SIGNATURES), f"binding mismatch: {sorted(syms ^ set(_native.SIGNATURES))}"
+    for s in syms:
+        assert hasattr(lib, s)
+
+
+def test_version_and_error_string(lib):
+    assert lib.univst_abi_version() == 1
+    assert isinstance(lib.univst_last_error(), bytes)
+
+
+def test_no_product_import_of_oracle():
+    """the product path must never route through the oracle (or any CPU fallback)."""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "univst_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "from oracle" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_native_missing_library_fails_loudly(monkeypatch):
+    from univst_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "_LIB_PATH", "/nonexistent/libunivst_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU or eager-PyTorch fallback"):
+        _native.load()
+
+
+def test_unet_forward_refuses_cpu():
+    import torch
+    from univst_amd.backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel
+    unet = UNetPseudo3DConditionModel(block_out_channels=(32, 64, 64, 64), cross_attention_dim=32, attention_head_dim=2,
+                                      norm_num_groups=8)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        unet(torch.zeros(1, 4, 2, 16, 16), 1, torch.zeros(1, 77, 32))

@@ -1,0 +1,213 @@
+"""GPU parity of every stand-alone HIP operator, called through the C ABI (univst_amd._native), against
+the oracle / a plain torch fp32 restatement of the same op on the same seeded inputs.
+
+Tolerances (fp16 storage, fp32 accumulation): outputs are compared with the fp32 result computed from the SAME
+fp16-rounded inputs; allowed error = 2 fp16 ulp of the output magnitude + accumulation noise, expressed as
+|err| <= atol + rtol*|ref| with rtol = 2e-3 (2 ulp of fp16 = 2*2^-11 ~ 1e-3) unless stated otherwise.
+Integer / index outputs (masks, warped uint8 frames) must be bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref, maskprop_ref, flow_ref, synth_inputs as si  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from univst_amd import _native
+    _native.load()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _native
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().cuda()
+
+
+def close(got, ref, rtol=2e-3, atol=None):
+    got = got.float()
+    ref = ref.float().to(got.device)
+    if atol is None:
+        atol = 2e-3 * ref.abs().max().item() + 1e-6
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bad.any(), f"max err {err.max().item():.4e} (ref max {ref.abs().max().item():.3e}), {int(bad.sum())} bad"
+
+
+def test_tr16_probe(nat):
+    """ds_read_b64_tr_b16 semantics the attention kernel relies on: lane (g, l15), element j reads
+    row g*4+j, column l15 of a row-major [16][16] fp16 image."""
+    out = nat.debug_tr16().cpu().view(64, 4)
+    for lane in range(64):
+        g, l15 = lane >> 4, lane & 15
+        for j in range(4):
+            assert out[lane, j].item() == (g * 4 + j) * 16 + l15, (lane, j, out[lane].tolist())
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (129, 96, 72), (4096, 960, 320), (77 * 3, 64, 32),
+                                   (1000, 4, 2880)])
+def test_linear(nat, M, N, K):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+    close(nat.linear(x, w), x.float() @ w.float().T)
+    close(nat.linear(x, w, bias=b, residual=r), x.float() @ w.float().T + b.float() + r.float())
+
+
+def test_linear_geglu(nat):
+    M, C = 520, 64
+    x, w, b = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=1 / 8), rnd(8 * C, seed=3)
+    h = x.float() @ w.float().T + b.float()
+    a, gate = h.chunk(2, dim=-1)
+    ref = a * F.gelu(gate)
+    # interleave rows: [16 x | 16 gate] blocks
+    idx = []
+    for q in range(4 * C // 16):
+        idx += list(range(16 * q, 16 * q + 16)) + list(range(4 * C + 16 * q, 4 * C + 16 * q + 16))
+    idx = torch.tensor(idx).cuda()
+    close(nat.linear(x, w[idx].contiguous(), bias=b[idx].contiguous(), geglu=True), ref)
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def conv_w(w):   # [Co,Ci,3,3] -> [Co,9,Ci]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1, w.shape[1]).contiguous()
+
+
+@pytest.mark.parametrize("Ci,Co,H,stride,up", [(32, 64, 16, 1, False), (64, 32, 16, 2, False), (32, 32, 8, 1, True),
+                                               (8, 32, 16, 1, False), (320, 320, 16, 1, False), (96, 160, 12, 1, False)])
+def test_conv3x3(nat, Ci, Co, H, stride, up):
+    imgs = 6
+    x = rnd(imgs, Ci, H, H, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci))
+    b = rnd(Co, seed=3)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1)
+    got = nat.conv_nhwc(nhwc(x), conv_w(w), bias=b, upsample=up, stride=stride)
+    close(got, nhwc(ref))
+
+
+def test_conv_concat_rowbias_residual(nat):
+    imgs, Fr, C1, C2, Co, H = 6, 2, 64, 32, 64, 8      # 3 "branches" x 2 frames
+    x1, x2 = rnd(imgs, C1, H, H, seed=1), rnd(imgs, C2, H, H, seed=2)
+    w = rnd(Co, C1 + C2, 3, 3, seed=3, scale=0.05)
+    b, rb, res = rnd(Co, seed=4), rnd(imgs // Fr, Co, seed=5), rnd(imgs, Co, H, H, seed=6)
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), w.float(), b.float(), padding=1)
+    ref = ref + rb.float().repeat_interleave(Fr, 0)[:, :, None, None] + res.float()
+    got = nat.conv_nhwc(nhwc(x1), conv_w(w), bias=b, x2=nhwc(x2), rowbias=rb, rows_per_rowbias=Fr * H * H, residual=nhwc(res))
+    close(got, nhwc(ref))
+    # 1x1 shortcut over the virtual concat
+    w1 = rnd(Co, C1 + C2, 1, 1, seed=7, scale=0.1)
+    ref1 = F.conv2d(torch.cat([x1, x2], 1).float(), w1.float(), b.float())
+    close(nat.conv_nhwc(nhwc(x1), conv_w(w1), bias=b, x2=nhwc(x2)), nhwc(ref1))
+
+
+@pytest.mark.parametrize("C1,C2,G,H", [(32, 0, 8, 8), (64, 32, 8, 8), (640, 320, 32, 8), (320, 0, 32, 16), (1280, 1280, 32, 8)])
+def test_groupnorm_5d_and_per_frame(nat, C1, C2, G, H):
+    B, Fr = 3, 4
+    x1 = rnd(B * Fr, C1, H, H, seed=1) * 2 + 0.5
+    x2 = rnd(B * Fr, C2, H, H, seed=2) if C2 else None
+    C = C1 + C2
+    gam, bet = rnd(C, seed=3) * 0.1 + 1, rnd(C, seed=4) * 0.1
+    full = torch.cat([x1, x2], 1) if C2 else x1
+    x5 = full.float().view(B, Fr, C, H, H).permute(0, 2, 1, 3, 4)
+    ref5 = F.silu(F.group_norm(x5, G, gam.float(), bet.float(), 1e-5)).permute(0, 2, 1, 3, 4).reshape(B * Fr, C, H, H)
+    got5 = nat.groupnorm_nhwc(nhwc(x1), gam, bet, G, 1e-5, Fr * H * H, silu=True, x2=None if x2 is None else nhwc(x2))
+    close(got5, nhwc(ref5))
+    ref4 = F.group_norm(full.float(), G, gam.float(), bet.float(), 1e-6)
+    got4 = nat.groupnorm_nhwc(nhwc(x1), gam, bet, G, 1e-6, H * H, silu=False, x2=None if x2 is None else nhwc(x2))
+    close(got4, nhwc(ref4))
+
+
+@pytest.mark.parametrize("C", [32, 320, 640, 1280])
+def test_layernorm(nat, C):
+    x = rnd(777, C, seed=1) * 3 + 1
+    g, b = rnd(C, seed=2) * 0.1 + 1, rnd(C, seed=3) * 0.1
+    close(nat.layernorm(x, g, b), F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5))
+
+
+def sdpa_ref(q, k, v, heads):
+    return unet_ref.sdpa(q.float(), k.float(), v.float(), heads)
+
+
+@pytest.mark.parametrize("heads,d,N,Fr,mode", [(2, 16, 64, 3, "stock"), (2, 32, 256, 4, "pnp"), (8, 40, 576, 2, "stock"),
+                                                (8, 80, 128, 3, "pnp"), (8, 160, 64, 2, "stock"), (4, 64, 200, 2, "stock")])
+def test_attention_sparse_causal(nat, heads, d, N, Fr, mode):
+    """fused-QKV layout, K/V gathered by pointer from {prev, (cur), first} frames of the same branch."""
+    B, C = 3, heads * d
+    qkv = rnd(B * Fr, N, 3 * C, seed=1)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    index = [-1, 0, "first"] if mode == "stock" else [-1, "first"]
+    kk = unet_ref.sparse_causal_gather(k.float().contiguous().cpu(), Fr, index).cuda()
+    vv = unet_ref.sparse_causal_gather(v.float().contiguous().cpu(), Fr, index).cuda()
+    ref = sdpa_ref(q.contiguous(), kk, vv, heads)
+    rows = []
+    for b in range(B):
+        for f in range(Fr):
+            prev, first = b * Fr + max(f - 1, 0), b * Fr
+            rows.append([prev, b * Fr + f, first] if mode == "stock" else [prev, first])
+    src = torch.tensor(rows, dtype=torch.int32).cuda()
+    got = nat.attention(q, k, v, src, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C)
+    close(got, ref, rtol=4e-3)
+
+
+def test_attention_cross_77(nat):
+    heads, d, N, BF, B = 8, 40, 300, 6, 3
+    C = heads * d
+    q = rnd(BF, N, C, seed=1)
+    kv = rnd(B, 77, 2 * C, seed=2)
+    k, v = kv[..., :C], kv[..., C:]
+    src = torch.tensor([[i // 2] for i in range(BF)], dtype=torch.int32).cuda()
+    ref = sdpa_ref(q, k.float().repeat_interleave(2, 0), v.float().repeat_interleave(2, 0), heads)
+    got = nat.attention(q, k, v, src, heads, ldkv=2 * C, Nkv=77, C_=C)
+    close(got, ref, rtol=4e-3)
+
+
+def test_attention_softmax_spike(nat):
+    """force large running-max jumps between key tiles (online-softmax rescale path)."""
+    heads, d, N = 2, 32, 256
+    C = heads * d
+    q, k, v = rnd(1, N, C, seed=1), rnd(1, N, C, seed=2), rnd(1, N, C, seed=3)
+    k[0, 200] = q[0, 5] * 6           # a spike in the 4th tile for query 5
+    k[0, 70] = q[0, 9] * 5
+    src = torch.zeros(1, 1, dtype=torch.int32).cuda()
+    close(nat.attention(q, k, v, src, heads), sdpa_ref(q, k, v, heads), rtol=4e-3)
+
+
+@pytest.mark.parametrize("C,N,Fr,idx", [(64, 64, 4, 0), (320, 256, 3, 13), (1280, 64, 2, 25)])
+def test_attention_adain_shift(nat, C, N, Fr, idx):
+    qkv = (rnd(3 * Fr * N, 3 * C, seed=1) * 1.5 + 0.2)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().cpu().view(3 * Fr, N, C) for i in range(3))
+    rq, rk, rv = unet_ref.pnp_shift(q, k, v, idx)
+    beta = unet_ref.pnp_beta(idx)
+    got = nat.attention_adain_shift_(qkv.clone(), Fr, N, C, 0.65, beta, 3.0).float().cpu()
+    ref = torch.cat([rq.reshape(-1, C), rk.reshape(-1, C), rv.reshape(-1, C)], 1)
+    close(got, ref, rtol=3e-3)
+    assert torch.equal(got[:2 * Fr * N], qkv[:2 * Fr * N].float().cpu()), "content/style rows must be untouched"
+
+
+def test_latent_adain_and_elementwise(nat, golden):
+    g = golden("g1_latent_adain")
+    got = nat.latent_adain(g["cnt"].half().cuda(), g["sty"].half().cuda())
+    close(got, unet_ref.latent_adain(g["cnt"].half().float(), g["sty"].half().float()), rtol=3e-3)
+    c, s = rnd(1, 4, 16, 64, 64, seed=1), rnd(1, 4, 16, 64, 64, seed=2) * 0.7 + 0.1
+    close(nat.latent_adain(c, s), unet_ref.latent_adain(c.float(), s.float()), rtol=3e-3)
+    close(nat.axpby(c, s, 0.97, -0.13), 0.97 * c.float() - 0.13 * s.float())
+    m = (torch.rand(16, 64, 64) > 0.5).half().cuda()
+    close(nat.mask_blend(c, s, m), (1 - m.float()) * c.float() + m.float() * s.float())
+    close(nat.mask_blend(c, s, None), c.float())
+
+
+def test_mask_resize(nat):
+    m = torch.from_numpy((si.disc_masks(16, 512, 512) > 0).astype(np.uint8)).cuda()
+    ref = F.interpolate(m[None].float(), size=(64, 64), mode="bilinear", align_corners=False)[0]
+    got = nat.mask_resize(m, 64, 64)
+    assert torch.equal(got.float(), ref), "mask resize values {0,.25,.5,.75,1} must be exact"

@@ -1,0 +1,228 @@
+"""ctypes binding of libunivst_hip.so (include/univst.h).
+
+There is NO fallback: if the shared library is missing or a call fails, a RuntimeError is raised.  torch is
+used only as the owner of device memory and of the current HIP stream.
+"""
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunivst_hip.so")
+_lib = None
+
+
+class UnetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
+                ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int), ("attention_heads", C.c_int),
+                ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("flip_sin_to_cos", C.c_int),
+                ("freq_shift", C.c_float)]
+
+
+class PnP(C.Structure):
+    _fields_ = [("registered", C.c_int), ("idx", C.c_int), ("eta1", C.c_float), ("eta2", C.c_float),
+                ("alpha", C.c_float), ("gamma", C.c_float)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+KVEXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+# name -> (restype, argtypes); kept in sync with include/univst.h (tests/test_abi.py checks both ways)
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "univst_last_error": (C.c_char_p, []),
+    "univst_abi_version": (_I, []),
+    "univst_unet_create": (_I, [C.POINTER(UnetCfg), C.POINTER(_P)]),
+    "univst_unet_destroy": (_I, [_P]),
+    "univst_unet_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L), _I, _P]),
+    "univst_unet_finalize": (_I, [_P, _P]),
+    "univst_unet_reserve": (_I, [_P, _I, _I, _I, _I]),
+    "univst_unet_forward": (_I, [_P, _P, _F, _P, _I, _I, _I, _I, _I, C.POINTER(PnP), _P, _P, _I, _P]),
+    "univst_unet_set_comm": (_I, [_P, _I, _I, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
+    "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
+    "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "univst_groupnorm_workspace_bytes": (_L, [_L, _I, _I]),
+    "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
+    "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
+    "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "univst_attention_adain_shift": (_I, [_P, _L, _I, _I, _I, _F, _F, _F, _P, _P]),
+    "univst_latent_adain": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "univst_axpby": (_I, [_P, _P, _P, _F, _F, _L, _P]),
+    "univst_mask_blend": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "univst_mask_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "univst_maskprop_workspace_bytes": (_L, [_I, _I, _I]),
+    "univst_maskprop_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "univst_maskprop_finalize": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "univst_warp_accumulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "univst_accumulate_u8": (_I, [_P, _P, _L, _P]),
+    "univst_window_store": (_I, [_P, _F, _P, _L, _P]),
+    "univst_debug_tr16": (_I, [_P, _P]),
+    "univst_profile_enable": (_I, [_I]),
+    "univst_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+}
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (no GPU needed for loading)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} not found: build it with `python __graft_entry__.py build` (or `make`); "
+                               "univst_amd has no CPU or eager-PyTorch fallback")
+        lib = C.CDLL(_LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().univst_last_error().decode(errors="replace")
+        raise RuntimeError(f"libunivst_hip {what} failed (code {rc}): {msg}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f16(t: torch.Tensor, name="tensor"):
+    if not (t.is_cuda and t.dtype == torch.float16 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous fp16 CUDA/HIP tensor, got {t.dtype} {t.device} "
+                         f"contiguous={t.is_contiguous()}")
+    return t
+
+
+# --------------------------------------------------------------------------- stand-alone operator wrappers
+def linear(x, w, bias=None, residual=None, geglu=False, out=None):
+    """y[M,N] = x[M,K] w[N,K]^T (+bias)(+residual); geglu: w/bias rows pre-interleaved, N/2 output columns."""
+    _f16(x), _f16(w)
+    M, K = x.shape
+    N = w.shape[0]
+    No = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, No, device=x.device, dtype=torch.float16)
+    check(load().univst_linear(ptr(x), K, ptr(w), ptr(bias), ptr(residual), No, ptr(out), No, M, N, K, int(geglu),
+                               stream_ptr()), "linear")
+    return out
+
+
+def conv_nhwc(x1, w, bias=None, x2=None, upsample=False, stride=1, rowbias=None, rows_per_rowbias=1, residual=None):
+    """x1 [imgs,Hs,Ws,C1] (+ x2 [imgs,Hs,Ws,C2]) NHWC, w [Cout,taps,C1+C2] -> [imgs,Ho,Wo,Cout]."""
+    _f16(x1), _f16(w)
+    imgs, Hs, Ws, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cout, taps, _ = w.shape
+    He, We = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    Ho = (He - 1) // stride + 1 if taps == 9 else He
+    Wo = (We - 1) // stride + 1 if taps == 9 else We
+    out = torch.empty(imgs, Ho, Wo, Cout, device=x1.device, dtype=torch.float16)
+    check(load().univst_conv_nhwc(ptr(x1), ptr(x2), C1, C2, imgs, Hs, Ws, int(upsample), stride, taps, ptr(w), ptr(bias),
+                                  ptr(rowbias), rows_per_rowbias, ptr(residual), ptr(out), Cout, stream_ptr()), "conv_nhwc")
+    return out
+
+
+def groupnorm_nhwc(x1, gamma, beta, groups, eps, rows_per_stat, silu=False, x2=None):
+    _f16(x1)
+    C1 = x1.shape[-1]
+    C2 = 0 if x2 is None else x2.shape[-1]
+    rows = x1.numel() // C1
+    ws = torch.empty(max(1, load().univst_groupnorm_workspace_bytes(rows, rows_per_stat, groups) // 4), device=x1.device,
+                     dtype=torch.float32)
+    out = torch.empty(*x1.shape[:-1], C1 + C2, device=x1.device, dtype=torch.float16)
+    check(load().univst_groupnorm_nhwc(ptr(x1), ptr(x2), C1, C2, rows, rows_per_stat, groups, eps, ptr(gamma), ptr(beta),
+                                       int(silu), ptr(out), ptr(ws), stream_ptr()), "groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    _f16(x)
+    C_ = x.shape[-1]
+    out = torch.empty_like(x)
+    check(load().univst_layernorm(ptr(x), ptr(out), ptr(gamma), ptr(beta), x.numel() // C_, C_, eps, stream_ptr()),
+          "layernorm")
+    return out
+
+
+def attention(q, k, v, src_idx, heads, ldq=None, ldkv=None, Nq=None, Nkv=None, C_=None):
+    """q [BF,Nq,C], k/v [S,Nkv,C] (S source blocks), src_idx int32 [BF,nsrc] -> [BF,Nq,C]."""
+    BF, Nq_, Cq = q.shape
+    C_ = C_ or Cq
+    out = torch.empty(BF, Nq_, C_, device=q.device, dtype=torch.float16)
+    check(load().univst_attention(ptr(q), ldq or q.stride(1), ptr(k), ptr(v), ldkv or k.stride(1), ptr(out), C_,
+                                  ptr(src_idx), src_idx.shape[1], BF, Nq_, Nkv or k.shape[1], heads, C_ // heads,
+                                  stream_ptr()), "attention")
+    return out
+
+
+def attention_adain_shift_(qkv, F, N, C_, alpha, beta, gamma):
+    """in place on the fused [3*F*N, 3C] buffer."""
+    _f16(qkv)
+    ws = torch.empty(4 * F * 2 * C_, device=qkv.device, dtype=torch.float32)
+    check(load().univst_attention_adain_shift(ptr(qkv), qkv.shape[-1], F, N, C_, alpha, beta, gamma, ptr(ws), stream_ptr()),
+          "attention_adain_shift")
+    return qkv
+
+
+def latent_adain(cnt, sty, out=None):
+    _f16(cnt), _f16(sty)
+    _, Cl, F, H, W = cnt.shape
+    out = torch.empty_like(cnt) if out is None else out
+    check(load().univst_latent_adain(ptr(cnt), ptr(sty), ptr(out), Cl, F, H * W, stream_ptr()), "latent_adain")
+    return out
+
+
+def axpby(x, e, cx, ce, out=None):
+    _f16(x), _f16(e)
+    out = torch.empty_like(x) if out is None else out
+    check(load().univst_axpby(ptr(x), ptr(e), ptr(out), cx, ce, x.numel(), stream_ptr()), "axpby")
+    return out
+
+
+def mask_blend(a, b, m, out=None):
+    """(1-m)*a + m*b with a,b [1,C,F,h,w], m [F,h,w] fp16 or None."""
+    _f16(a), _f16(b)
+    out = torch.empty_like(a) if out is None else out
+    Cl = a.shape[1]
+    check(load().univst_mask_blend(ptr(a), ptr(b), ptr(m), ptr(out), Cl, a.numel() // Cl, stream_ptr()), "mask_blend")
+    return out
+
+
+def mask_resize(mask_u8, h, w):
+    """uint8 {0,1} [F,H,W] -> fp16 [F,h,w] (torch bilinear, align_corners=False)."""
+    F, H, W = mask_u8.shape
+    out = torch.empty(F, h, w, device=mask_u8.device, dtype=torch.float16)
+    check(load().univst_mask_resize(ptr(mask_u8), ptr(out), F, H, W, h, w, stream_ptr()), "mask_resize")
+    return out
+
+
+def debug_tr16():
+    out = torch.empty(256, device="cuda", dtype=torch.float32)
+    check(load().univst_debug_tr16(ptr(out), stream_ptr()), "debug_tr16")
+    return out
+
+
+PROFILE_CLASSES = ("gemm", "conv", "attention", "groupnorm", "layernorm", "adain")
+
+
+def profile_enable(on: bool):
+    check(load().univst_profile_enable(int(on)), "profile_enable")
+
+
+def profile_collect():
+    """-> {class: dict(ms=, launches=, flops=, bytes=)} for everything launched since profile_enable(True)."""
+    n = len(PROFILE_CLASSES)
+    ms, cnt, fl, by = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    check(load().univst_profile_collect(ms, cnt, fl, by, n), "profile_collect")
+    return {PROFILE_CLASSES[i]: dict(ms=ms[i], launches=cnt[i], flops=fl[i], bytes=by[i]) for i in range(n)}

@@ -1,0 +1,190 @@
+"""Host-side mirror of ``SpatioTemporalStableDiffusionPipeline``
+(backbones/video_diffusion_sd/pipelines/stable_diffusion.py:45-834 of the reference).
+
+Same constructor, same ``reconstruction`` / ``video_style_transfer`` signatures, result in ``.images``.
+The denoising loops run through univst_amd.engine (HIP kernels; device-resident latents/masks); the VAE and
+the CLIP text encoder stay stock PyTorch-ROCm modules supplied by the caller (third-party weights).
+Extras (all optional, reference defaults unchanged): ``smoother='pixel'`` + ``flow_fn`` switch on the
+sliding-window smoothing that is dead code in the reference (:715), ``content_inv_latents`` /
+``style_inv_latents`` / ``masks`` accept in-memory tensors instead of paths, ``output_type='latent'`` skips
+the VAE, ``skip_dead_branches`` (see engine.transfer_loop).
+"""
+import inspect
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from .... import engine
+from ....src.util import load_ddim_latents_at_t, load_mask
+from ..pnp_utils import latent_adain, register_time  # noqa: F401  (re-exported like the reference module)
+
+
+class StableDiffusionPipelineOutput:
+    def __init__(self, images, nsfw_content_detected=None):
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+
+class SpatioTemporalStableDiffusionPipeline:
+    _optional_components = []
+
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler):
+        if hasattr(scheduler.config, "steps_offset") and scheduler.config.steps_offset != 1:
+            raise ValueError("scheduler.config.steps_offset must be 1 (SD-v1.5 DDIM configuration)")
+        if hasattr(scheduler.config, "clip_sample") and scheduler.config.clip_sample is True:
+            raise ValueError("scheduler.config.clip_sample must be False")
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+        boc = getattr(getattr(vae, "config", None), "block_out_channels", (1, 1, 1, 1))
+        self.vae_scale_factor = 2 ** (len(boc) - 1)
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    # ------------------------------------------------------------------ prompt (stable_diffusion.py:193-308)
+    def _encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt):
+        batch_size = len(prompt) if isinstance(prompt, list) else 1
+        ti = self.tokenizer(prompt, padding="max_length", max_length=self.tokenizer.model_max_length, truncation=True,
+                            return_tensors="pt")
+        am = None
+        if getattr(getattr(self.text_encoder, "config", None), "use_attention_mask", False):
+            am = ti.attention_mask.to(device)
+        emb = self.text_encoder(ti.input_ids.to(device), attention_mask=am)[0]
+        bs, seq, _ = emb.shape
+        emb = emb.repeat(1, num_images_per_prompt, 1).view(bs * num_images_per_prompt, seq, -1)
+        if do_classifier_free_guidance:
+            if negative_prompt is None:
+                un = [""] * batch_size
+            elif isinstance(negative_prompt, str):
+                un = [negative_prompt]
+            else:
+                un = negative_prompt
+            ui = self.tokenizer(un, padding="max_length", max_length=ti.input_ids.shape[-1], truncation=True, return_tensors="pt")
+            ue = self.text_encoder(ui.input_ids.to(device), attention_mask=am)[0]
+            ue = ue.repeat(1, num_images_per_prompt, 1).view(batch_size * num_images_per_prompt, ue.shape[1], -1)
+            emb = torch.cat([ue, emb])
+        return emb
+
+    # ------------------------------------------------------------------ VAE (stable_diffusion.py:369-394, 793-834)
+    def _vae_decode(self, latents, num_frames, chunk=16):
+        latents = latents.permute(0, 2, 1, 3, 4).flatten(0, 1)
+        latents = 1 / self.vae.config.scaling_factor * latents
+        fwd = self.vae.forward
+        accepts = "num_frames" in set(inspect.signature(fwd).parameters.keys())
+        frames = []
+        for i in range(0, latents.shape[0], chunk):
+            z = latents[i:i + chunk].to(next(self.vae.parameters()).dtype)
+            kw = {"num_frames": z.shape[0]} if accepts else {}
+            frames.append(self.vae.decode(z, **kw).sample)
+        return (torch.cat(frames, dim=0) / 2 + 0.5).clamp(0, 1)
+
+    def decode_latents(self, latents, num_frames=None, decode_chunk_size=16):
+        F_ = latents.shape[2]
+        frames = self._vae_decode(latents, F_, decode_chunk_size)
+        n, c, h, w = frames.shape
+        frames = frames.view(n // F_, F_, c, h, w).permute(0, 1, 3, 4, 2)
+        return frames.cpu().float().numpy()
+
+    def get_images_from_latents(self, latents, decode_chunk_size=16):
+        """uint8 frames [b,3,F,H,W] on the device (the reference returns numpy, :793-819)."""
+        F_ = latents.shape[2]
+        frames = self._vae_decode(latents * self.vae.config.scaling_factor / 0.18215, F_, decode_chunk_size)
+        frames = (frames.float() * 255).round().to(torch.uint8)
+        n, c, h, w = frames.shape
+        return frames.view(n // F_, F_, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
+
+    def get_latent_image(self, frames_u8):
+        """uint8 [b,3,F,H,W] -> latents [b,4,F,h,w] (:821-834; consumes torch RNG like the reference)."""
+        b, c, F_, H, W = frames_u8.shape
+        img = frames_u8.permute(0, 2, 1, 3, 4).reshape(b * F_, c, H, W).float() / 127.5 - 1.0
+        img = img.to(device=self.device, dtype=next(self.vae.parameters()).dtype)
+        z = self.vae.encode(img).latent_dist.sample()
+        z = z.view(b, F_, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+        return (0.18215 * z).to(torch.float16).contiguous()
+
+    def return_to_timestep(self, timestep, sample, sample_stablized, schedules):
+        return engine.return_to_timestep(schedules, timestep, sample, sample_stablized)
+
+    # ------------------------------------------------------------------ reconstruction (:479-628)
+    @torch.no_grad()
+    def reconstruction(self, prompt, height=512, width=512, num_inference_steps=50, video_length=8, guidance_scale=7.5,
+                       negative_prompt=None, num_images_per_prompt=1, eta=0.0, generator=None, latents=None,
+                       output_type="tensor", return_dict=True, callback=None, callback_steps=1, **kwargs):
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0")
+        device = self._execution_device
+        cfg = guidance_scale > 1.0
+        text = self._encode_prompt(prompt, device, num_images_per_prompt, cfg, negative_prompt)
+        self.scheduler.set_timesteps(num_inference_steps)
+        if latents is None:
+            shape = (1, self.unet.config.in_channels, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+            latents = torch.randn(shape, generator=generator, device=device, dtype=text.dtype)
+        latents = latents.to(device=device, dtype=torch.float16).contiguous()
+        for i, t in enumerate(self.scheduler.timesteps):
+            x = torch.cat([latents] * 2) if cfg else latents
+            eps = self.unet(x, t, encoder_hidden_states=text).sample
+            if cfg:
+                eu, et = eps.chunk(2)
+                eps = (eu.float() + guidance_scale * (et.float() - eu.float())).to(torch.float16)
+            latents = engine.ddim_step(self.scheduler, eps, t, latents)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, latents)
+        return self._finish(latents, output_type, return_dict)
+
+    def _finish(self, latents, output_type, return_dict):
+        if output_type == "latent":
+            image = latents
+        else:
+            image = self.decode_latents(latents)
+            if output_type == "tensor":
+                image = torch.from_numpy(image)
+        if not return_dict:
+            return (image, None)
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None)
+
+    # ------------------------------------------------------------------ video_style_transfer (:631-780)
+    @torch.no_grad()
+    def video_style_transfer(self, prompt, num_inference_steps=50, negative_prompt=None, num_videos_per_prompt=1, eta=0.0,
+                             generator=None, latents=None, output_type="tensor", return_dict=True, callback=None,
+                             callback_steps=1, content_inv_path=None, style_inv_path=None, mask_path=None,
+                             content_inv_latents=None, style_inv_latents=None, masks=None, smoother=None, flow_fn=None,
+                             skip_dead_branches=False, **kwargs):
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0")
+        device = self._execution_device
+        n = num_inference_steps
+        pe = self._encode_prompt(prompt, device, num_videos_per_prompt, False, negative_prompt)
+        ie = self._encode_prompt("", device, num_videos_per_prompt, False, None)
+        text3 = torch.cat([ie, ie, pe])
+        F_ = latents.shape[2]
+        if content_inv_latents is None:
+            content_inv_latents = [load_ddim_latents_at_t(k, content_inv_path) for k in range(n + 1)]
+        if style_inv_latents is None:
+            style_inv_latents = [load_ddim_latents_at_t(k, style_inv_path) for k in range(n + 1)]
+        if masks is None and mask_path:
+            masks = load_mask(mask_path, n_frames=F_)
+        sm = None
+        if smoother is not None:
+            if smoother != "pixel":
+                print("error")
+                return
+            if flow_fn is None or masks is None:
+                raise ValueError("smoother='pixel' needs flow_fn (RAFT stand-in) and masks (the reference raises NameError "
+                                 "without mask_path, stable_diffusion.py:751)")
+            from ....src.cal_optica_flow import sliding_window_smooth
+            m01 = masks.to(device).to(torch.uint8).reshape(-1, *masks.shape[-2:])
+
+            def sm(i, t, lat, eps):
+                x0 = engine.pred_original_sample(self.scheduler, eps, t, lat)
+                frames = self.get_images_from_latents(x0)
+                frames = sliding_window_smooth(frames, flow_fn, m01)
+                return engine.return_to_timestep(self.scheduler, t, lat, self.get_latent_image(frames))
+        cb = (lambda i, t, l: callback(i, t, l) if i % callback_steps == 0 else None) if callback is not None else None
+        latents = engine.transfer_loop(self, latents.to(device), text3, content_inv_latents, style_inv_latents, masks, n,
+                                       smoother=sm, callback=cb, skip_dead_branches=skip_dead_branches)
+        return self._finish(latents, output_type, return_dict)

@@ -1,0 +1,184 @@
+// extern "C" surface of libunivst_hip.so (include/univst.h).  Thin argument checking + dispatch.
+#include <stdarg.h>
+
+#include <new>
+
+#include "../../include/univst.h"
+#include "common.h"
+#include "kernels.h"
+#include "unet.h"
+
+static thread_local char g_err[1024] = "";
+void uv_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* uv_get_error() { return g_err; }
+
+#define H(p) ((const half_t*)(p))
+#define HM(p) ((half_t*)(p))
+#define S(p) ((hipStream_t)(p))
+
+struct univst_unet {
+    UNet impl;
+};
+
+extern "C" {
+
+const char* univst_last_error(void) { return g_err; }
+int univst_abi_version(void) { return 1; }
+
+int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
+    UV_REQUIRE(cfg && out, "unet_create: null argument");
+    UV_REQUIRE(cfg->attention_heads > 0 && cfg->norm_num_groups > 0 && cfg->layers_per_block > 0, "unet_create: bad config");
+    for (int i = 0; i < 4; ++i) {
+        int c = cfg->block_out_channels[i];
+        UV_REQUIRE(c % 8 == 0 && c % cfg->norm_num_groups == 0 && c % cfg->attention_heads == 0 && (c / cfg->attention_heads) % 8 == 0,
+                   "unet_create: block_out_channels[%d]=%d must be divisible by 8, groups and heads (head_dim multiple of 8)", i, c);
+    }
+    UV_REQUIRE(cfg->cross_attention_dim % 8 == 0, "unet_create: cross_attention_dim must be a multiple of 8");
+    univst_unet* h = new (std::nothrow) univst_unet();
+    UV_REQUIRE(h, "unet_create: out of host memory");
+    h->impl.cfg = *cfg;
+    *out = h;
+    return UV_OK;
+}
+int univst_unet_destroy(univst_unet* h) {
+    delete h;
+    return UV_OK;
+}
+int univst_unet_load_tensor(univst_unet* h, const char* key, const void* p, int dtype, const int64_t* shape, int ndim, void* s) {
+    UV_REQUIRE(h, "null handle");
+    return h->impl.load_tensor(key, p, dtype, shape, ndim, S(s));
+}
+int univst_unet_finalize(univst_unet* h, void* s) {
+    UV_REQUIRE(h, "null handle");
+    return h->impl.finalize(S(s));
+}
+int univst_unet_reserve(univst_unet* h, int B, int F, int Hh, int W) {
+    UV_REQUIRE(h, "null handle");
+    return h->impl.reserve(B, F, Hh, W);
+}
+int univst_unet_forward(univst_unet* h, const void* sample, float t, const void* text, int B, int F, int Hh, int W, int text_len,
+                        const univst_pnp* pnp, void* eps, void* feat, int ft_index, void* s) {
+    UV_REQUIRE(h && sample && text && eps, "unet_forward: null argument");
+    return h->impl.forward(H(sample), t, H(text), B, F, Hh, W, text_len, pnp, HM(eps), HM(feat), ft_index, S(s));
+}
+int univst_unet_set_comm(univst_unet* h, int rank, int world, univst_allreduce_fn ar, univst_kv_exchange_fn kv, void* user) {
+    UV_REQUIRE(h && world >= 1 && rank >= 0 && rank < world, "set_comm: bad rank/world");
+    h->impl.rank = rank;
+    h->impl.world = world;
+    h->impl.allreduce = ar;
+    h->impl.kv_exchange = kv;
+    h->impl.comm_user = user;
+    return UV_OK;
+}
+
+int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                  int M, int N, int K, int geglu, void* s) {
+    UV_REQUIRE(X && W && Y, "linear: null argument");
+    GemmParams g;
+    g.X = H(X); g.ldx = ldx; g.W = H(W); g.bias = H(bias); g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy;
+    g.M = M; g.N = N; g.K = K; g.geglu = geglu;
+    return uv_launch_gemm(g, 0, S(s));
+}
+int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int up, int stride, int taps,
+                     const void* W, const void* bias, const void* rowbias, int rows_per_rb, const void* R, void* Y, int Cout,
+                     void* s) {
+    UV_REQUIRE(X1 && W && Y, "conv: null argument");
+    UV_REQUIRE((X2 != nullptr) == (C2 > 0), "conv: X2/C2 mismatch");
+    UV_REQUIRE(stride == 1 || stride == 2, "conv: stride %d", stride);
+    GemmParams g;
+    g.X = H(X1); g.X2 = H(X2); g.C1 = C1; g.C2 = C2; g.Hs = Hs; g.Ws = Ws; g.up = up ? 1 : 0; g.stride = stride; g.taps = taps;
+    const int He = Hs << g.up, We = Ws << g.up;
+    g.Ho = taps == 9 ? (He - 1) / stride + 1 : He;
+    g.Wo = taps == 9 ? (We - 1) / stride + 1 : We;
+    g.M = imgs * g.Ho * g.Wo; g.N = Cout; g.K = taps * (C1 + C2);
+    g.W = H(W); g.bias = H(bias); g.rowbias = H(rowbias); g.rows_per_rb = rows_per_rb > 0 ? rows_per_rb : 1;
+    g.R = H(R); g.ldr = Cout; g.Y = HM(Y); g.ldy = Cout;
+    return uv_launch_gemm(g, 1, S(s));
+}
+int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups) {
+    if (rows_per_stat <= 0) return 0;
+    return (int64_t)uv_groupnorm_workspace_floats((int)(rows / rows_per_stat), groups) * 4;
+}
+int univst_groupnorm_nhwc(const void* X1, const void* X2, int C1, int C2, int64_t rows, int rows_per_stat, int groups, float eps,
+                          const void* gamma, const void* beta, int silu, void* Y, void* ws, void* s) {
+    UV_REQUIRE(X1 && gamma && beta && Y && ws, "groupnorm: null argument");
+    return uv_launch_groupnorm(H(X1), H(X2), C1, C2, rows, rows_per_stat, groups, eps, H(gamma), H(beta), silu, HM(Y), (float*)ws,
+                               S(s));
+}
+int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta, int64_t rows, int C, float eps, void* s) {
+    UV_REQUIRE(X && Y && gamma && beta, "layernorm: null argument");
+    return uv_launch_layernorm(H(X), C, HM(Y), C, H(gamma), H(beta), rows, C, eps, S(s));
+}
+int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
+                     const int32_t* src_idx, int nsrc, int BF, int Nq, int Nkv, int heads, int d, void* s) {
+    UV_REQUIRE(q && k && v && out && src_idx, "attention: null argument");
+    AttnParams a;
+    a.q = H(q); a.k = H(k); a.v = H(v); a.o = HM(out); a.ldq = ldq; a.ldkv = ldkv; a.ldo = ldo; a.src_idx = src_idx; a.nsrc = nsrc;
+    a.BF = BF; a.Nq = Nq; a.Nkv = Nkv; a.heads = heads; a.d = d;
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+    return uv_launch_attention(a, S(s));
+}
+int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, float alpha, float beta, float gamma, void* ws, void* s) {
+    UV_REQUIRE(qkv && ws, "adain_shift: null argument");
+    float* w = (float*)ws;
+    return uv_launch_adain_shift(HM(qkv), ld, F, N, C, w, w + (long)F * 2 * C, alpha, beta, gamma, S(s));
+}
+int univst_latent_adain(const void* cnt, const void* sty, void* out, int C, int F, int HW, void* s) {
+    UV_REQUIRE(cnt && sty && out, "latent_adain: null argument");
+    return uv_launch_latent_adain(H(cnt), H(sty), HM(out), C, F, HW, S(s));
+}
+int univst_axpby(const void* x, const void* e, void* out, float cx, float ce, int64_t n, void* s) {
+    UV_REQUIRE(x && e && out, "axpby: null argument");
+    return uv_launch_axpby(H(x), H(e), HM(out), cx, ce, n, S(s));
+}
+int univst_mask_blend(const void* a, const void* b, const void* m, void* out, int C, int64_t FHW, void* s) {
+    UV_REQUIRE(a && b && out, "mask_blend: null argument");
+    return uv_launch_mask_blend(H(a), H(b), H(m), HM(out), C, FHW, S(s));
+}
+int univst_mask_resize(const uint8_t* mask, void* out, int F, int Hh, int W, int h, int w, void* s) {
+    UV_REQUIRE(mask && out, "mask_resize: null argument");
+    return uv_launch_mask_resize(mask, HM(out), F, Hh, W, h, w, S(s));
+}
+int univst_debug_tr16(float* out, void* s) { return uv_launch_tr16_probe(out, S(s)); }
+int univst_profile_enable(int on) {
+    uv_prof_enable(on);
+    return UV_OK;
+}
+int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int ncls) {
+    UV_REQUIRE(ms && count && flops && bytes && ncls >= 1 && ncls <= 16, "profile_collect: bad arguments");
+    long c[16];
+    int rc = uv_prof_collect(ms, c, flops, bytes, ncls);
+    for (int i = 0; i < ncls; ++i) count[i] = c[i];
+    return rc;
+}
+
+int64_t univst_maskprop_workspace_bytes(int hw, int Nsrc, int C) { return uv_maskprop_workspace_bytes(hw, Nsrc, C); }
+int univst_maskprop_frame(const float* feat_tar, const float* feat_src, const float* segs_src, float* segs_tar, int hw, int Nsrc,
+                          int C, int ncls, float T, int topk, void* ws, void* s) {
+    UV_REQUIRE(feat_tar && feat_src && segs_src && segs_tar && ws, "maskprop_frame: null argument");
+    return uv_launch_maskprop_frame(feat_tar, feat_src, segs_src, segs_tar, hw, Nsrc, C, ncls, T, topk, ws, S(s));
+}
+int univst_maskprop_finalize(const float* segs, uint8_t* out, int ncls, int h, int w, int Hh, int W, void* ws, void* s) {
+    UV_REQUIRE(segs && out && ws, "maskprop_finalize: null argument");
+    return uv_launch_maskprop_finalize(segs, out, ncls, h, w, Hh, W, ws, S(s));
+}
+int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int Hh, int W,
+                           float thr, void* s) {
+    UV_REQUIRE(key && now && fwd && bwd && acc, "warp_accumulate: null argument");
+    return uv_launch_warp_accumulate(key, now, fwd, bwd, acc, Hh, W, thr, S(s));
+}
+int univst_accumulate_u8(const uint8_t* f, float* acc, int64_t n, void* s) {
+    UV_REQUIRE(f && acc, "accumulate_u8: null argument");
+    return uv_launch_accumulate_u8(f, acc, n, S(s));
+}
+int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n, void* s) {
+    UV_REQUIRE(acc && dst && weight > 0.f, "window_store: bad argument");
+    return uv_launch_window_store(acc, weight, dst, n, S(s));
+}
+
+}  // extern "C"

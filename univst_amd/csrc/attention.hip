@@ -1,0 +1,235 @@
+// Flash-style multi-source attention for gfx950: sparse-causal spatial self-attention (keys/values of
+// each frame gathered BY POINTER from {prev, (cur), first} frames of its branch — never concatenated) and
+// the 77-token text cross-attention, in one kernel.
+//
+// Per block: 4 waves x (QB*16) query rows of one (frame, head); K/V tiles of 64 keys staged in LDS.
+// "Swapped" formulation (guide T12): S^T = K Q^T so a lane owns ONE query column -> the running max /
+// sum are lane-local (+2 xor-shuffles across the 4 lane groups), the O^T accumulator is rescaled by a
+// lane-uniform scalar, and exp'd probabilities feed the second MFMA straight from registers:
+//     S^T[key][q]  = mfma_16x16x32( A = K[key][d..],  B = Q^T[d..][q] )
+//     O^T[d][q]   += mfma_16x16x32( A = V^T[d][key..] (ds_read_b64_tr_b16 from row-major V), B = P^T[key..][q] )
+// The k-slot <-> key permutation of the second MFMA is chosen so P^T needs no cross-lane movement.
+// Softmax statistics in fp32, exp2 with the 1/sqrt(d)*log2(e) scale folded in.
+// Replaces: attention.py:384-420 (SparseCausalAttention gather + SDPA), pnp_utils.py:59-92 (PnP gather +
+// SDPA), diffusers AttnProcessor2_0 SDPA for attn2.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int KT = 64;   // keys per LDS tile
+
+template <int DPAD, int DV16, int QB>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    constexpr int KSTR = lds_stride_bytes(DPAD * 2) / 2;
+    constexpr int DV = DV16 * 16;
+    constexpr int VSTR = lds_stride_bytes(DV * 2) / 2;
+    constexpr int KS = DPAD / 32;
+    __shared__ __attribute__((aligned(16))) half_t smem[KT * KSTR + KT * VSTR];
+    half_t* Ks = smem;
+    half_t* Vs = smem + KT * KSTR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % nqb;
+    const int h = (lid / nqb) % p.heads;
+    const int bf = lid / (nqb * p.heads);
+    const int d = p.d;
+
+    // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
+    h8 qf[QB][KS];
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int dc = ks * 32 + g * 8;
+            qf[qb][ks] = (qrow < p.Nq && dc < d)
+                             ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * d + dc)
+                             : zero8;
+        }
+    }
+
+    f4 o[DV16][QB];
+    float mrun[QB], lrun[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = -INFINITY;
+        lrun[qb] = 0.f;
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) o[dv][qb] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int s = 0; s < p.nsrc; ++s) {
+        const long src = p.src_idx[bf * p.nsrc + s];
+        for (int t0 = 0; t0 < p.Nkv; t0 += KT) {
+            __syncthreads();
+            // ---- stage K tile [64][DPAD] and V tile [64][DV] (zero-filled beyond d / Nkv)
+            constexpr int KCH = DPAD / 8;
+            for (int idx = tid; idx < KT * KCH; idx += 256) {
+                const int row = idx / KCH, ch = idx - row * KCH;
+                const bool ok = (t0 + row < p.Nkv) && (ch * 8 < d);
+                h8 v = ok ? *reinterpret_cast<const h8*>(p.k + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
+                *reinterpret_cast<h8*>(&Ks[row * KSTR + ch * 8]) = v;
+            }
+            constexpr int VCH = DV / 8;
+            for (int idx = tid; idx < KT * VCH; idx += 256) {
+                const int row = idx / VCH, ch = idx - row * VCH;
+                const bool ok = (t0 + row < p.Nkv) && (ch * 8 < d);
+                h8 v = ok ? *reinterpret_cast<const h8*>(p.v + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
+                *reinterpret_cast<h8*>(&Vs[row * VSTR + ch * 8]) = v;
+            }
+            __syncthreads();
+
+            // ---- S^T = K Q^T
+            f4 sc[4][QB];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    h8 a = *reinterpret_cast<const h8*>(&Ks[(kb * 16 + l15) * KSTR + ks * 32 + g * 8]);
+#pragma unroll
+                    for (int qb = 0; qb < QB; ++qb)
+                        sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qb][ks], sc[kb][qb], 0, 0, 0);
+                }
+            }
+            const bool tail = t0 + KT > p.Nkv;
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                // scale, mask, row max (lane-local over 16 values, then across the 4 lane groups)
+                float mx = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = sc[kb][qb][r] * p.scale_log2e;
+                        if (tail && (t0 + kb * 16 + g * 4 + r >= p.Nkv)) v = -INFINITY;
+                        sc[kb][qb][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mnew = fmaxf(mrun[qb], mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+                mrun[qb] = mnew;
+                float rs = 0.f;
+                h8 pb[2];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e = __builtin_amdgcn_exp2f(sc[kb][qb][r] - mnew);
+                        rs += e;
+                        pb[kb >> 1][(kb & 1) * 4 + r] = (half_t)e;
+                    }
+                lrun[qb] = lrun[qb] * alpha + rs;
+#pragma unroll
+                for (int dv = 0; dv < DV16; ++dv) {
+                    o[dv][qb][0] *= alpha; o[dv][qb][1] *= alpha; o[dv][qb][2] *= alpha; o[dv][qb][3] *= alpha;
+                }
+                // ---- O^T += V^T P^T  (two 32-key chunks)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                    for (int dv = 0; dv < DV16; ++dv) {
+                        const half_t* vp = &Vs[(c * 32 + g * 4 + (l15 >> 2)) * VSTR + dv * 16 + (l15 & 3) * 4];
+                        fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
+                        fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * VSTR));
+                        h8 a;
+                        a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
+                        a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
+                        o[dv][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[c], o[dv][qb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- finalize: O^T[d = dv*16 + g*4 + r][q = l15] / l
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = lrun[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
+        if (qrow >= p.Nq) continue;
+        half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * d;
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) {
+            const int dc = dv * 16 + g * 4;
+            if (dc < d) {
+                h4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                *reinterpret_cast<h4*>(op + dc) = ov;
+            }
+        }
+    }
+}
+
+// lane l of a 64-lane wave reports what ds_read_b64_tr_b16 returned for a known LDS image (bring-up aid).
+__global__ void tr16_probe_kernel(float* out) {
+    __shared__ __attribute__((aligned(16))) half_t sm[64 * 16];
+    for (int i = threadIdx.x; i < 64 * 16; i += 64) sm[i] = (half_t)(float)i;   // value = row*16 + col
+    __syncthreads();
+    const int lane = threadIdx.x, l15 = lane & 15, g = lane >> 4;
+    const half_t* vp = &sm[(g * 4 + (l15 >> 2)) * 16 + (l15 & 3) * 4];
+    fh4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
+    for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (float)v[j];
+}
+
+template <int DPAD, int DV16>
+int launch_attn(const AttnParams& p, hipStream_t stream) {
+    const int QB = p.Nq >= 512 ? 2 : 1;
+    const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
+    dim3 grid(nqb * p.heads * p.BF), block(256);
+    if (QB == 2) hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1>), grid, block, 0, stream, p);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+}  // namespace
+
+static int attn_dispatch(const AttnParams& p, hipStream_t stream);
+
+int uv_launch_attention(const AttnParams& p, hipStream_t stream) {
+    UV_REQUIRE(p.d % 8 == 0, "attention: head_dim=%d must be a multiple of 8", p.d);
+    UV_REQUIRE(p.nsrc >= 1 && p.Nkv >= 1 && p.Nq >= 1, "attention: empty problem");
+    UV_REQUIRE(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must be multiples of 8");
+    const double nkv = (double)p.nsrc * p.Nkv;
+    uv_prof_begin(UV_CLS_ATTN, 4.0 * p.BF * p.heads * (double)p.Nq * nkv * p.d,
+                  2.0 * p.BF * p.heads * p.d * (2.0 * p.Nq + 2.0 * nkv), stream);
+    int rc = attn_dispatch(p, stream);
+    uv_prof_end(stream);
+    return rc;
+}
+
+static int attn_dispatch(const AttnParams& p, hipStream_t stream) {
+    switch (p.d) {
+
+        case 16: return launch_attn<32, 1>(p, stream);
+        case 32: return launch_attn<32, 2>(p, stream);
+        case 40: return launch_attn<64, 3>(p, stream);
+        case 64: return launch_attn<64, 4>(p, stream);
+        case 80: return launch_attn<96, 5>(p, stream);
+        case 160: return launch_attn<160, 10>(p, stream);
+        default:
+            uv_set_error("attention: head_dim=%d not instantiated (16,32,40,64,80,160)", p.d);
+            return UV_ERR_UNSUPPORTED;
+    }
+}
+
+int uv_launch_tr16_probe(float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(tr16_probe_kernel, dim3(1), dim3(64), 0, stream, out);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}

@@ -1,0 +1,79 @@
+// Common device/host helpers for the UniVST gfx950 kernels (CDNA4 only; no CUDA paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#define UV_OK 0
+#define UV_ERR_ARG (-1)
+#define UV_ERR_HIP (-2)
+#define UV_ERR_UNSUPPORTED (-3)
+#define UV_ERR_STATE (-4)
+
+void uv_set_error(const char* fmt, ...);
+const char* uv_get_error();
+
+#define UV_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            uv_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));    \
+            return UV_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define UV_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            uv_set_error(__VA_ARGS__);        \
+            return UV_ERR_ARG;                \
+        }                                     \
+    } while (0)
+
+#define UV_LAUNCH_CHECK()                                                                         \
+    do {                                                                                          \
+        hipError_t _e = hipGetLastError();                                                        \
+        if (_e != hipSuccess) {                                                                   \
+            uv_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+            return UV_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+// LDS row stride (bytes) that makes the 16-row x 4-chunk ds_read_b128 fragment pattern and the
+// ds_read_b64_tr_b16 pattern conflict-free on gfx950: stride % 64 == 32 (brute-forced against the
+// per-instruction lane groups of MI355X_MICROARCH.md §LDS).
+constexpr int lds_stride_bytes(int row_bytes) {
+    int s = (row_bytes + 63) / 64 * 64 + 32;
+    return (s - 64 >= row_bytes) ? s - 64 : s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+// XCD-aware bijective block remap (8 XCDs, block b observed on XCD b%8): consecutive logical ids
+// land on the same XCD so tiles that share an operand panel hit the same 4 MiB L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    if (nwg < nx) return bid;
+    int q = nwg / nx, r = nwg % nx, xcd = bid % nx, idx = bid / nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

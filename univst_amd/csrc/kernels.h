@@ -1,0 +1,72 @@
+// Internal launcher interface shared by the kernel translation units, the UNet graph and the C ABI.
+#pragma once
+#include "common.h"
+
+struct GemmParams {
+    // Y[m][n] = epilogue(sum_k X[m][k] W[n][k])
+    const half_t* X = nullptr;   // MODE 0: [M,K] (row stride ldx).  MODE 1: NHWC source 1 [imgs, Hs, Ws, C1]
+    const half_t* X2 = nullptr;  // MODE 1: NHWC source 2 (virtual channel concat) or null
+    const half_t* W = nullptr;   // [N,K], K contiguous (conv: K = tap*(C1+C2)+c)
+    half_t* Y = nullptr;
+    long ldx = 0, ldy = 0;
+    int M = 0, N = 0, K = 0;
+    // MODE 1 geometry
+    int C1 = 0, C2 = 0, Hs = 1, Ws = 1, up = 0, Ho = 1, Wo = 1, stride = 1, taps = 1;
+    // epilogue
+    const half_t* bias = nullptr;      // [N]
+    const half_t* rowbias = nullptr;   // [M / rows_per_rb, N]  (time-embedding add per branch)
+    int rows_per_rb = 1;
+    const half_t* R = nullptr;         // residual [M, ldr]
+    long ldr = 0;
+    const half_t* bias2 = nullptr;     // second bias added after fp16 rounding (attn_temporal bias)
+    int geglu = 0;                     // W rows interleaved [16 x | 16 gate]; writes N/2 columns x*gelu(gate)
+};
+
+struct AttnParams {
+    const half_t* q = nullptr;   // row (bf*Nq + i), head h at column h*d
+    const half_t* k = nullptr;   // row (src*Nkv + j)
+    const half_t* v = nullptr;
+    half_t* o = nullptr;
+    long ldq = 0, ldkv = 0, ldo = 0;
+    const int* src_idx = nullptr;   // [BF][nsrc] source frame (row-block) of every key segment
+    int nsrc = 1, BF = 0, Nq = 0, Nkv = 0, heads = 0, d = 0;
+    float scale_log2e = 0.f;
+};
+
+int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
+int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
+                           hipStream_t stream);
+int uv_groupnorm_workspace_floats(int S, int G);
+int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G, float eps,
+                        const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part, hipStream_t stream);
+int uv_launch_layernorm(const half_t* x, long ldx, half_t* y, long ldy, const half_t* gamma, const half_t* beta, long rows,
+                        int C, float eps, hipStream_t stream);
+int uv_launch_attention(const AttnParams& p, hipStream_t stream);
+int uv_launch_tr16_probe(float* out, hipStream_t stream);
+int uv_launch_colstats(const half_t* x, long ld, int F, int N, int ncols, float* mean, float* stdv, hipStream_t stream);
+int uv_launch_adain_shift(half_t* qkv, long ld, int F, int N, int C, float* mean, float* stdv, float alpha, float beta,
+                          float gamma, hipStream_t stream);
+int uv_launch_latent_adain(const half_t* cnt, const half_t* sty, half_t* out, int Cl, int F, int HW, hipStream_t stream);
+int uv_launch_ncfhw_to_nhwc(const half_t* x, half_t* y, int B, int Cl, int F, int HW, int CP, hipStream_t s);
+int uv_launch_nhwc_to_ncfhw(const half_t* x, int ldx, half_t* y, int B, int Cl, int F, int HW, hipStream_t s);
+int uv_launch_timestep_embed(float t, half_t* out, int B, int dim, int flip, float shift, hipStream_t s);
+int uv_launch_axpby(const half_t* x, const half_t* e, half_t* out, float cx, float ce, long n, hipStream_t s);
+int uv_launch_mask_blend(const half_t* a, const half_t* b, const half_t* m, half_t* out, int Cl, long FHW, hipStream_t s);
+int uv_launch_mask_resize(const uint8_t* mask, half_t* out, int F, int H, int W, int h, int w, hipStream_t s);
+int uv_launch_add_bias_rows(half_t* x, const half_t* b, long rows, int C, hipStream_t s);
+int64_t uv_maskprop_workspace_bytes(int hw, int Nsrc, int C);
+int uv_launch_maskprop_frame(const float* feat_tar, const float* feat_src, const float* segs_src, float* segs_tar, int hw,
+                             int Nsrc, int C, int ncls, float T, int topk, void* ws, hipStream_t s);
+int uv_launch_maskprop_finalize(const float* segs, uint8_t* out, int ncls, int h, int w, int H, int W, void* ws, hipStream_t s);
+int uv_launch_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int H, int W,
+                              float thr, hipStream_t s);
+int uv_launch_accumulate_u8(const uint8_t* f, float* acc, long n, hipStream_t s);
+int uv_launch_window_store(const float* acc, float weight, uint8_t* dst, long n, hipStream_t s);
+
+// ---- optional per-class HIP-event profiling (prof.hip)
+enum { UV_CLS_GEMM = 0, UV_CLS_CONV = 1, UV_CLS_ATTN = 2, UV_CLS_GROUPNORM = 3, UV_CLS_LAYERNORM = 4, UV_CLS_ADAIN = 5, UV_NCLS = 6 };
+void uv_prof_enable(int on);
+bool uv_prof_on();
+void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s);
+void uv_prof_end(hipStream_t s);
+int uv_prof_collect(double* ms, long* count, double* flops, double* bytes, int ncls);

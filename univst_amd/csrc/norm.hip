@@ -1,0 +1,230 @@
+// GroupNorm (cross-frame 5-D and per-frame 4-D statistics) + SiLU, LayerNorm, and the column-statistics
+// primitive shared with the PnP AdaIN (pnp.hip).  All HBM-bound; activations are NHWC fp16 [rows, C].
+//
+// GroupNorm is two launches: (1) deterministic partial sums per (stat unit, row chunk, group) -> `part`
+// [S, nchunk, G, 2] fp32 — this small buffer is what a multi-GPU frame shard all-reduces;
+// (2) finalize (each block re-reduces the <=128 chunk partials of its stat unit) + normalise + affine
+// (+SiLU) + store.  The input may be the virtual channel-concat of two sources (UNet skip connection),
+// groups may straddle the two; the output is one contiguous [rows, C1+C2] tensor.
+// Replaces: resnet.py:338,369 + unet_3d_condition.py:439 (5-D GroupNorm eps 1e-5 + SiLU),
+// attention.py:69-71,121 (per-frame GroupNorm eps 1e-6), attention.py:289-343 (LayerNorms).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// Threads are laid out (tr, tc): tc indexes a 16-byte column chunk (8 channels), tr a row phase.
+// Each thread keeps 8 per-channel sums over its rows; block-level reduction is through LDS in a fixed
+// order (deterministic).
+__global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* __restrict__ s2, int C1, int C2,
+                                  int rows_per_stat, int rows_per_chunk, int G, float* __restrict__ part) {
+    extern __shared__ float sm[];                    // [TR][C] sums, [TR][C] sumsq
+    const int C = C1 + C2, TC = C / 8, TR = blockDim.x / TC;
+    const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
+    const int s = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int c0 = tc * 8;
+    const bool second = c0 >= C1;
+    const half_t* src = second ? s2 : s1;
+    const int cs = second ? C2 : C1, co = second ? c0 - C1 : c0;
+    float sum[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+    if (tr < TR) {
+        const long rbase = (long)s * rows_per_stat;
+        const int r0 = chunk * rows_per_chunk;
+        const int r1 = min(r0 + rows_per_chunk, rows_per_stat);
+        for (int r = r0 + tr; r < r1; r += TR) {
+            h8 v = *reinterpret_cast<const h8*>(src + (rbase + r) * cs + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[e];
+                sum[e] += f;
+                sq[e] += f * f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sm[tr * C + c0 + e] = sum[e];
+            sm[(TR + tr) * C + c0 + e] = sq[e];
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int gi = threadIdx.x; gi < G; gi += blockDim.x) {
+        float a = 0.f, b = 0.f;
+        for (int c = gi * cpg; c < (gi + 1) * cpg; ++c)
+            for (int t = 0; t < TR; ++t) {
+                a += sm[t * C + c];
+                b += sm[(TR + t) * C + c];
+            }
+        float* o = part + (((long)s * nchunk + chunk) * G + gi) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+
+__global__ void gn_apply_kernel(const half_t* __restrict__ s1, const half_t* __restrict__ s2, int C1, int C2,
+                                int rows_per_stat, int rows_per_block, int G, int nchunk, float eps,
+                                const float* __restrict__ part, const half_t* __restrict__ gamma,
+                                const half_t* __restrict__ beta, int silu, half_t* __restrict__ out) {
+    extern __shared__ float sm[];                    // [G] mean, [G] rstd
+    const int C = C1 + C2, TC = C / 8, TR = blockDim.x / TC;
+    const int s = blockIdx.y;
+    const int cpg = C / G;
+    for (int gi = threadIdx.x; gi < G; gi += blockDim.x) {
+        double a = 0.0, b = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float* pp = part + (((long)s * nchunk + ch) * G + gi) * 2;
+            a += pp[0];
+            b += pp[1];
+        }
+        double cnt = (double)rows_per_stat * cpg;
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sm[gi] = (float)mean;
+        sm[G + gi] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
+    if (tr >= TR) return;
+    const int c0 = tc * 8;
+    const bool second = c0 >= C1;
+    const half_t* src = second ? s2 : s1;
+    const int cs = second ? C2 : C1, co = second ? c0 - C1 : c0;
+    float sc[8], sh[8];
+    {
+        h8 gv = *reinterpret_cast<const h8*>(gamma + c0);
+        h8 bv = *reinterpret_cast<const h8*>(beta + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int gi = (c0 + e) / cpg;
+            float rs = sm[G + gi], mu = sm[gi];
+            sc[e] = rs * (float)gv[e];
+            sh[e] = (float)bv[e] - mu * sc[e];
+        }
+    }
+    const long rbase = (long)s * rows_per_stat;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, rows_per_stat);
+    for (int r = r0 + tr; r < r1; r += TR) {
+        h8 v = *reinterpret_cast<const h8*>(src + (rbase + r) * cs + co);
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (float)v[e] * sc[e] + sh[e];
+            if (silu) y = silu_f(y);
+            o[e] = (half_t)y;
+        }
+        *reinterpret_cast<h8*>(out + (rbase + r) * C + c0) = o;
+    }
+}
+
+// LayerNorm over the last dim, one wave per row, row kept in registers (two-pass variance).
+template <int MAXCH>
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx, half_t* __restrict__ y,
+                                                        long ldy, const half_t* __restrict__ gamma,
+                                                        const half_t* __restrict__ beta, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = C / 8;
+    h8 v[MAXCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+            v[i] = *reinterpret_cast<const h8*>(x + row * ldx + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        }
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = (float)v[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        int ch = lane + 64 * i;
+        if (ch < nch) {
+            h8 gv = *reinterpret_cast<const h8*>(gamma + ch * 8);
+            h8 bv = *reinterpret_cast<const h8*>(beta + ch * 8);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mean) * rstd * (float)gv[e] + (float)bv[e]);
+            *reinterpret_cast<h8*>(y + row * ldy + ch * 8) = o;
+        }
+    }
+}
+
+}  // namespace
+
+static int gn_geometry(int C, int* block) {
+    int TC = C / 8;
+    int TR = 256 / TC;
+    if (TR < 1) TR = 1;
+    *block = TC * TR;
+    return TR;
+}
+
+int uv_groupnorm_workspace_floats(int S, int G) { return S * 128 * G * 2; }
+
+int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G,
+                        float eps, const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part,
+                        hipStream_t stream) {
+    const int C = C1 + C2;
+    UV_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channels must be multiples of 8 (C1=%d C2=%d)", C1, C2);
+    UV_REQUIRE(C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
+    UV_REQUIRE(C / 8 <= 1024, "groupnorm: C=%d too large", C);
+    UV_REQUIRE(rows % rows_per_stat == 0, "groupnorm: rows=%ld not a multiple of rows_per_stat=%d", rows, rows_per_stat);
+    const int S = (int)(rows / rows_per_stat);
+    int block;
+    const int TR = gn_geometry(C, &block);
+    // chunks: <=128 per stat unit, >= ~64 rows per thread-row when the tensor is big
+    int nchunk = (rows_per_stat + TR * 32 - 1) / (TR * 32);
+    if (nchunk > 128) nchunk = 128;
+    if (nchunk < 1) nchunk = 1;
+    const int rpc = (rows_per_stat + nchunk - 1) / nchunk;
+    nchunk = (rows_per_stat + rpc - 1) / rpc;
+    uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
+    size_t lds1 = (size_t)2 * TR * C * sizeof(float);
+    UV_REQUIRE(lds1 <= 160 * 1024, "groupnorm: LDS %zu too large", lds1);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, S), dim3(block), lds1, stream, s1, s2, C1, C2, rows_per_stat, rpc,
+                       G, part);
+    UV_LAUNCH_CHECK();
+    int nblk = (rows_per_stat + TR * 16 - 1) / (TR * 16);
+    if (nblk > 2048 / (S > 0 ? 1 : 1)) nblk = 2048;
+    if (nblk < 1) nblk = 1;
+    const int rpb = (rows_per_stat + nblk - 1) / nblk;
+    nblk = (rows_per_stat + rpb - 1) / rpb;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, S), dim3(block), 2 * G * sizeof(float), stream, s1, s2, C1, C2,
+                       rows_per_stat, rpb, G, nchunk, eps, part, gamma, beta, silu, out);
+    uv_prof_end(stream);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int uv_launch_layernorm(const half_t* x, long ldx, half_t* y, long ldy, const half_t* gamma, const half_t* beta,
+                        long rows, int C, float eps, hipStream_t stream) {
+    UV_REQUIRE(C % 8 == 0 && C <= 64 * 8 * 4, "layernorm: C=%d unsupported (multiple of 8, <= 2048)", C);
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int nch = (C / 8 + 63) / 64;
+    uv_prof_begin(UV_CLS_LAYERNORM, 0.0, 4.0 * (double)rows * C, stream);
+    if (nch <= 1) hipLaunchKernelGGL((layernorm_kernel<1>), grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, (int)rows, C, eps);
+    else if (nch == 2) hipLaunchKernelGGL((layernorm_kernel<2>), grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, (int)rows, C, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<4>), grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, (int)rows, C, eps);
+    uv_prof_end(stream);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}

@@ -1,0 +1,51 @@
+// Optional per-kernel-class HIP-event timing (bench.py roofline leg).  Off by default: zero overhead.
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+struct Rec {
+    int cls;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+bool g_on = false;
+std::vector<Rec> g_recs;
+}  // namespace
+
+void uv_prof_enable(int on) { g_on = on != 0; }
+bool uv_prof_on() { return g_on; }
+void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s) {
+    if (!g_on) return;
+    Rec r{cls, nullptr, nullptr, flops, bytes};
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    (void)hipEventRecord(r.a, s);
+    g_recs.push_back(r);
+}
+void uv_prof_end(hipStream_t s) {
+    if (!g_on || g_recs.empty()) return;
+    (void)hipEventRecord(g_recs.back().b, s);
+}
+int uv_prof_collect(double* ms, long* count, double* flops, double* bytes, int ncls) {
+    for (int i = 0; i < ncls; ++i) {
+        ms[i] = 0;
+        count[i] = 0;
+        flops[i] = 0;
+        bytes[i] = 0;
+    }
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls < ncls) {
+            ms[r.cls] += t;
+            count[r.cls] += 1;
+            flops[r.cls] += r.flops;
+            bytes[r.cls] += r.bytes;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    return UV_OK;
+}

@@ -1,0 +1,60 @@
+// UNet handle internals (see unet.hip).
+#pragma once
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/univst.h"
+#include "common.h"
+
+typedef univst_pnp univst_pnp_t;
+
+struct WTensor {
+    half_t* ptr = nullptr;
+    std::vector<long> shape;
+};
+
+struct Act {   // NHWC activation: [imgs, H, W, C] fp16
+    half_t* p = nullptr;
+    int imgs = 0, H = 0, W = 0, C = 0;
+    long rows() const { return (long)imgs * H * W; }
+};
+
+struct Arena {   // first-fit allocator over one device slab; stream-ordered reuse
+    struct Block {
+        size_t off, size;
+        bool free;
+    };
+    char* base = nullptr;
+    size_t size = 0, high_water = 0;
+    std::vector<Block> blocks;
+    void* alloc(size_t bytes);
+    void release(void* p);
+    void reset();
+};
+
+struct UNet {
+    univst_unet_cfg cfg;
+    std::unordered_map<std::string, WTensor> weights, derived;
+    std::unordered_map<long, int*> idx_tables;
+    Arena arena;
+    bool finalized = false;
+    unsigned* d_counter = nullptr;
+    std::string missing;
+    // multi-GPU frame sharding hooks
+    int rank = 0, world = 1;
+    univst_allreduce_fn allreduce = nullptr;
+    univst_kv_exchange_fn kv_exchange = nullptr;
+    void* comm_user = nullptr;
+
+    ~UNet();
+    int load_tensor(const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, hipStream_t s);
+    int finalize(hipStream_t s);
+    int reserve(int B, int F, int H, int W);
+    int forward(const half_t* sample, float timestep, const half_t* text, int B, int F, int H, int W, int text_len,
+                const univst_pnp_t* pnp, half_t* eps_out, half_t* feat_out, int ft_index, hipStream_t s);
+    const WTensor* find(const std::string& k) const;
+    half_t* W(const std::string& k);
+    int derive_alloc(const std::string& k, std::vector<long> shape, half_t** out);
+    int missing_error();
+};

@@ -1,0 +1,616 @@
+// The whole pseudo-3D SD UNet forward as ONE host-side graph of gfx950 kernels (one C-ABI call per
+// denoising step).  Activations live in NHWC fp16 ([B*F*H*W, C] == the transformer's token layout), chosen
+// once at conv_in, so every rearrange/permute/cat/upsample of the reference disappears into kernel
+// addressing.  Weights are owned by the handle (device fp16 copies keyed by the reference state-dict
+// names) plus derived layouts built by finalize().  A first-fit arena supplies all activations; nothing is
+// allocated inside forward() after the first call for a geometry.
+//
+// Structure restated from: unet_3d_condition.py:306-443, unet_3d_blocks.py:129-645, attention.py:104-346,
+// resnet.py:335-394, pnp_utils.py:20-111.  Dead work of the reference that is skipped because it is an
+// exact identity for 2-D-initialised weights (verified at finalize): temporal conv1d (dirac, resnet.py:53-55)
+// and temporal attention (zero to_out weight => adds its bias, attention.py:233).
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "unet.h"
+
+namespace {
+
+__global__ void convert_f32_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (half_t)in[i];
+}
+// [Co,Ci,kh,kw] -> [Co,kh*kw,CiP] (zero padded channels)
+__global__ void permute_conv_weight_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int Co, int Ci, int taps,
+                                           int CiP) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)Co * taps * CiP;
+    if (i >= total) return;
+    int c = (int)(i % CiP);
+    int t = (int)((i / CiP) % taps);
+    int o = (int)(i / ((long)CiP * taps));
+    out[i] = c < Ci ? in[((long)o * Ci + c) * taps + t] : (half_t)0.f;
+}
+// GEGLU row interleave: out row (32q + j) = in row (16q + j), out row (32q+16+j) = in row (half + 16q + j)
+__global__ void geglu_interleave_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int rows, int cols) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    int c = (int)(i % cols), r = (int)(i / cols);
+    int q = r / 32, j = r % 32;
+    int src = j < 16 ? 16 * q + j : rows / 2 + 16 * q + (j - 16);
+    out[i] = in[(long)src * cols + c];
+}
+__global__ void count_not_dirac_kernel(const half_t* __restrict__ w, int Co, int Ci, int k, unsigned* cnt) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Co * Ci * k) return;
+    int t = (int)(i % k), ci = (int)((i / k) % Ci), co = (int)(i / ((long)k * Ci));
+    float expect = (co == ci && t == k / 2) ? 1.f : 0.f;
+    if ((float)w[i] != expect) atomicAdd(cnt, 1u);
+}
+__global__ void count_nonzero_kernel(const half_t* __restrict__ w, long n, unsigned* cnt) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (float)w[i] != 0.f) atomicAdd(cnt, 1u);
+}
+
+inline unsigned nb(long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ arena
+void* Arena::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        if (blocks[i].free && blocks[i].size >= bytes) {
+            if (blocks[i].size > bytes) {
+                Block rest{blocks[i].off + bytes, blocks[i].size - bytes, true};
+                blocks[i].size = bytes;
+                blocks.insert(blocks.begin() + i + 1, rest);
+            }
+            blocks[i].free = false;
+            size_t used = blocks[i].off + bytes;
+            if (used > high_water) high_water = used;
+            return base + blocks[i].off;
+        }
+    }
+    return nullptr;
+}
+void Arena::release(void* p) {
+    if (!p) return;
+    size_t off = (char*)p - base;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        if (blocks[i].off == off && !blocks[i].free) {
+            blocks[i].free = true;
+            if (i + 1 < blocks.size() && blocks[i + 1].free) {
+                blocks[i].size += blocks[i + 1].size;
+                blocks.erase(blocks.begin() + i + 1);
+            }
+            if (i > 0 && blocks[i - 1].free) {
+                blocks[i - 1].size += blocks[i].size;
+                blocks.erase(blocks.begin() + i);
+            }
+            return;
+        }
+    }
+}
+void Arena::reset() {
+    blocks.clear();
+    blocks.push_back(Block{0, size, true});
+}
+
+// ------------------------------------------------------------------------------------------ handle
+UNet::~UNet() {
+    for (auto& kv : weights) (void)hipFree(kv.second.ptr);
+    for (auto& kv : derived) (void)hipFree(kv.second.ptr);
+    for (auto& kv : idx_tables) (void)hipFree(kv.second);
+    if (arena.base) (void)hipFree(arena.base);
+    if (d_counter) (void)hipFree(d_counter);
+}
+
+int UNet::load_tensor(const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, hipStream_t s) {
+    UV_REQUIRE(key && dev_ptr && ndim >= 1 && ndim <= 5, "load_tensor: bad arguments");
+    long n = 1;
+    WTensor t;
+    for (int i = 0; i < ndim; ++i) {
+        n *= shape[i];
+        t.shape.push_back(shape[i]);
+    }
+    UV_REQUIRE(n > 0, "load_tensor(%s): empty tensor", key);
+    UV_HIP(hipMalloc(&t.ptr, n * sizeof(half_t)));
+    if (dtype == 0) {
+        UV_HIP(hipMemcpyAsync(t.ptr, dev_ptr, n * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+    } else if (dtype == 1) {
+        hipLaunchKernelGGL(convert_f32_f16_kernel, dim3(nb(n)), dim3(256), 0, s, (const float*)dev_ptr, t.ptr, n);
+        UV_LAUNCH_CHECK();
+    } else {
+        (void)hipFree(t.ptr);
+        uv_set_error("load_tensor(%s): dtype %d unsupported", key, dtype);
+        return UV_ERR_ARG;
+    }
+    auto it = weights.find(key);
+    if (it != weights.end()) {
+        UV_HIP(hipStreamSynchronize(s));
+        (void)hipFree(it->second.ptr);
+        weights.erase(it);
+    }
+    weights[key] = t;
+    finalized = false;
+    return UV_OK;
+}
+
+const WTensor* UNet::find(const std::string& k) const {
+    auto it = weights.find(k);
+    if (it != weights.end()) return &it->second;
+    auto jt = derived.find(k);
+    return jt == derived.end() ? nullptr : &jt->second;
+}
+
+half_t* UNet::W(const std::string& k) {
+    const WTensor* t = find(k);
+    if (!t) {
+        if (missing.empty()) missing = k;
+        return nullptr;
+    }
+    return t->ptr;
+}
+
+int UNet::derive_alloc(const std::string& k, std::vector<long> shape, half_t** out) {
+    auto it = derived.find(k);
+    if (it != derived.end()) {
+        (void)hipFree(it->second.ptr);
+        derived.erase(it);
+    }
+    long n = 1;
+    for (long v : shape) n *= v;
+    WTensor t;
+    t.shape = shape;
+    UV_HIP(hipMalloc(&t.ptr, n * sizeof(half_t)));
+    derived[k] = t;
+    *out = t.ptr;
+    return UV_OK;
+}
+
+int UNet::finalize(hipStream_t s) {
+    if (!d_counter) UV_HIP(hipMalloc(&d_counter, sizeof(unsigned)));
+    UV_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned), s));
+    std::vector<std::string> keys;
+    for (auto& kv : weights) keys.push_back(kv.first);
+    auto ends = [](const std::string& a, const char* suf) {
+        size_t n = strlen(suf);
+        return a.size() >= n && a.compare(a.size() - n, n, suf) == 0;
+    };
+    for (const std::string& k : keys) {
+        const WTensor& t = weights[k];
+        if (k.find("conv_temporal.weight") != std::string::npos) {
+            UV_REQUIRE(t.shape.size() == 3, "%s: expected [C,C,k]", k.c_str());
+            long n = t.shape[0] * t.shape[1] * t.shape[2];
+            hipLaunchKernelGGL(count_not_dirac_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, (int)t.shape[0], (int)t.shape[1],
+                               (int)t.shape[2], d_counter);
+        } else if (k.find("conv_temporal.bias") != std::string::npos || ends(k, "attn_temporal.to_out.0.weight")) {
+            long n = 1;
+            for (long v : t.shape) n *= v;
+            hipLaunchKernelGGL(count_nonzero_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, n, d_counter);
+        } else if (t.shape.size() == 4 && k.find("_temporal") == std::string::npos) {
+            // conv weights -> [Co][taps][CiP]
+            int Co = (int)t.shape[0], Ci = (int)t.shape[1], taps = (int)(t.shape[2] * t.shape[3]);
+            UV_REQUIRE(taps == 1 || taps == 9, "%s: only 1x1 / 3x3 convs are supported", k.c_str());
+            int CiP = (Ci + 7) / 8 * 8;
+            half_t* d;
+            int rc = derive_alloc(k + "#nhwc", {Co, taps, CiP}, &d);
+            if (rc) return rc;
+            long n = (long)Co * taps * CiP;
+            hipLaunchKernelGGL(permute_conv_weight_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, d, Co, Ci, taps, CiP);
+        } else if (ends(k, ".attn1.to_q.weight")) {
+            std::string p = k.substr(0, k.size() - strlen("to_q.weight"));
+            const WTensor *tk = find(p + "to_k.weight"), *tv = find(p + "to_v.weight");
+            UV_REQUIRE(tk && tv, "%s: to_k / to_v missing", p.c_str());
+            long C = t.shape[0], K = t.shape[1];
+            half_t* d;
+            int rc = derive_alloc(p + "qkv#fused", {3 * C, K}, &d);
+            if (rc) return rc;
+            UV_HIP(hipMemcpyAsync(d, t.ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            UV_HIP(hipMemcpyAsync(d + C * K, tk->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            UV_HIP(hipMemcpyAsync(d + 2 * C * K, tv->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+        } else if (ends(k, ".attn2.to_k.weight")) {
+            std::string p = k.substr(0, k.size() - strlen("to_k.weight"));
+            const WTensor* tv = find(p + "to_v.weight");
+            UV_REQUIRE(tv, "%s: to_v missing", p.c_str());
+            long C = t.shape[0], K = t.shape[1];
+            half_t* d;
+            int rc = derive_alloc(p + "kv#fused", {2 * C, K}, &d);
+            if (rc) return rc;
+            UV_HIP(hipMemcpyAsync(d, t.ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            UV_HIP(hipMemcpyAsync(d + C * K, tv->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+        } else if (ends(k, ".ff.net.0.proj.weight") || ends(k, ".ff.net.0.proj.bias")) {
+            int rows = (int)t.shape[0], cols = t.shape.size() > 1 ? (int)t.shape[1] : 1;
+            UV_REQUIRE(rows % 32 == 0, "%s: GEGLU width %d must be a multiple of 32", k.c_str(), rows);
+            half_t* d;
+            int rc = derive_alloc(k + "#geglu", {rows, cols}, &d);
+            if (rc) return rc;
+            hipLaunchKernelGGL(geglu_interleave_kernel, dim3(nb((long)rows * cols)), dim3(256), 0, s, t.ptr, d, rows, cols);
+        }
+    }
+    UV_LAUNCH_CHECK();
+    unsigned bad = 0;
+    UV_HIP(hipMemcpyAsync(&bad, d_counter, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    UV_HIP(hipStreamSynchronize(s));
+    if (bad) {
+        uv_set_error("finalize: %u *_temporal* weights differ from the identity initialisation (dirac conv1d / zero "
+                     "attn_temporal.to_out); trained temporal layers are not supported by this build", bad);
+        return UV_ERR_UNSUPPORTED;
+    }
+    finalized = true;
+    return UV_OK;
+}
+
+int UNet::reserve(int B, int F, int H, int Wd) {
+    const long rows0 = (long)B * F * H * Wd;
+    size_t need = (size_t)rows0 * cfg.block_out_channels[0] * 2 * 28 + (64u << 20);
+    if (arena.size < need) {
+        UV_HIP(hipDeviceSynchronize());
+        if (arena.base) UV_HIP(hipFree(arena.base));
+        arena.base = nullptr;
+        UV_HIP(hipMalloc((void**)&arena.base, need));
+        arena.size = need;
+    }
+    arena.reset();
+    // K/V source tables for this (B,F)
+    long key = ((long)B << 20) | F;
+    if (!idx_tables.count(key)) {
+        std::vector<int> t;
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < F; ++f) {   // stock: [-1, 0, 'first'] (attention.py:356)
+                t.push_back(b * F + (f > 0 ? f - 1 : 0));
+                t.push_back(b * F + f);
+                t.push_back(b * F);
+            }
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < F; ++f) {   // PnP: [-1, 'first'] (pnp_utils.py:25)
+                t.push_back(b * F + (f > 0 ? f - 1 : 0));
+                t.push_back(b * F);
+            }
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < F; ++f) t.push_back(b);   // text: one [77, C] block per branch
+        int* d;
+        UV_HIP(hipMalloc(&d, t.size() * sizeof(int)));
+        UV_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+        idx_tables[key] = d;
+    }
+    return UV_OK;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+#define RUN(x)                \
+    do {                      \
+        int _rc = (x);        \
+        if (_rc) return _rc;  \
+    } while (0)
+
+struct Fwd {
+    UNet& u;
+    hipStream_t s;
+    int B, F, text_len;
+    const univst_pnp_t* pnp;
+    half_t* emb = nullptr;     // [B, 4*C0]
+    const half_t* text = nullptr;
+    const int *idx_stock = nullptr, *idx_pnp = nullptr, *idx_text = nullptr;
+    float* gn_ws = nullptr;
+    float* ad_ws = nullptr;
+
+    half_t* alloc(long elems) {
+        half_t* p = (half_t*)u.arena.alloc((size_t)elems * sizeof(half_t));
+        if (!p) uv_set_error("activation arena exhausted (%zu bytes); call univst_unet_reserve with the right geometry", u.arena.size);
+        return p;
+    }
+    void free(void* p) { u.arena.release(p); }
+    half_t* W(const std::string& k) { return u.W(k); }
+
+    int groupnorm(const Act& a, const Act* b, int rows_per_stat, float eps, const std::string& p, int silu, half_t* out) {
+        return uv_launch_groupnorm(a.p, b ? b->p : nullptr, a.C, b ? b->C : 0, a.rows(), rows_per_stat, u.cfg.norm_num_groups,
+                                   eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s);
+    }
+    int conv(const Act& a, const Act* b, const std::string& p, int Cout, int taps, int stride, int up, const half_t* rowbias,
+             const half_t* R, Act* out) {
+        GemmParams g;
+        g.X = a.p;
+        g.X2 = b ? b->p : nullptr;
+        g.C1 = a.C;
+        g.C2 = b ? b->C : 0;
+        g.Hs = a.H;
+        g.Ws = a.W;
+        g.up = up;
+        g.stride = stride;
+        g.taps = taps;
+        const int He = a.H << up, We = a.W << up;
+        g.Ho = (taps == 9) ? (He + 2 - 3) / stride + 1 : He;
+        g.Wo = (taps == 9) ? (We + 2 - 3) / stride + 1 : We;
+        g.M = a.imgs * g.Ho * g.Wo;
+        g.N = Cout;
+        g.K = taps * (g.C1 + g.C2);
+        g.W = W(p + ".weight#nhwc");
+        g.bias = W(p + ".bias");
+        g.rowbias = rowbias;
+        g.rows_per_rb = F * g.Ho * g.Wo;
+        g.R = R;
+        g.ldr = Cout;
+        out->imgs = a.imgs;
+        out->H = g.Ho;
+        out->W = g.Wo;
+        out->C = Cout;
+        out->p = alloc(out->rows() * Cout);
+        if (!out->p) return UV_ERR_STATE;
+        g.Y = out->p;
+        g.ldy = Cout;
+        if (!g.W || !g.bias) return u.missing_error();
+        return uv_launch_gemm(g, 1, s);
+    }
+    int linear(const half_t* X, long ldx, long M, int K, const std::string& wkey, const std::string& bkey, int N, half_t* Y,
+               long ldy, const half_t* R = nullptr, long ldr = 0, const half_t* bias2 = nullptr, int geglu = 0) {
+        GemmParams g;
+        g.X = X;
+        g.ldx = ldx;
+        g.M = (int)M;
+        g.K = K;
+        g.N = N;
+        g.W = W(wkey);
+        g.bias = bkey.empty() ? nullptr : W(bkey);
+        g.Y = Y;
+        g.ldy = ldy;
+        g.R = R;
+        g.ldr = ldr;
+        g.bias2 = bias2;
+        g.geglu = geglu;
+        if (!g.W || (!bkey.empty() && !g.bias)) return u.missing_error();
+        return uv_launch_gemm(g, 0, s);
+    }
+
+    // resnet.py:335-394
+    int resblock(const std::string& p, const Act& x, const Act* skip, int Cout, Act* out) {
+        const int Cin = x.C + (skip ? skip->C : 0);
+        const int rps = F * x.H * x.W;
+        half_t* n1 = alloc(x.rows() * Cin);
+        if (!n1) return UV_ERR_STATE;
+        RUN(groupnorm(x, skip, rps, u.cfg.norm_eps, p + ".norm1", 1, n1));
+        half_t* tp = alloc((long)B * Cout);
+        if (!tp) return UV_ERR_STATE;
+        half_t *tw = W(p + ".time_emb_proj.weight"), *tb = W(p + ".time_emb_proj.bias");
+        if (!tw || !tb) return u.missing_error();
+        RUN(uv_launch_linear_small(emb, tw, tb, tp, B, Cout, 4 * u.cfg.block_out_channels[0], 1, s));
+        Act n1a{n1, x.imgs, x.H, x.W, Cin}, h;
+        RUN(conv(n1a, nullptr, p + ".conv1", Cout, 9, 1, 0, tp, nullptr, &h));
+        free(n1);
+        half_t* n2 = alloc(h.rows() * Cout);
+        if (!n2) return UV_ERR_STATE;
+        RUN(groupnorm(h, nullptr, rps, u.cfg.norm_eps, p + ".norm2", 1, n2));
+        free(h.p);
+        free(tp);
+        const half_t* res = x.p;
+        Act sc{};
+        if (u.find(p + ".conv_shortcut.weight")) {
+            RUN(conv(x, skip, p + ".conv_shortcut", Cout, 1, 1, 0, nullptr, nullptr, &sc));
+            res = sc.p;
+        } else {
+            UV_REQUIRE(!skip && x.C == Cout, "%s: no conv_shortcut but channel mismatch", p.c_str());
+        }
+        Act n2a{n2, x.imgs, x.H, x.W, Cout};
+        RUN(conv(n2a, nullptr, p + ".conv2", Cout, 9, 1, 0, nullptr, res, out));
+        free(n2);
+        if (sc.p) free(sc.p);
+        return UV_OK;
+    }
+
+    // attention.py:104-153 + :280-346 (+ pnp_utils.py:20-100 when pnp_layer)
+    int transformer(const std::string& p, const Act& x, bool pnp_layer, Act* out) {
+        const int C = x.C, heads = u.cfg.attention_heads, d = C / heads, N = x.H * x.W;
+        const long rows = x.rows();
+        const std::string b = p + ".transformer_blocks.0";
+        half_t* t0 = alloc(rows * C);
+        if (!t0) return UV_ERR_STATE;
+        RUN(groupnorm(x, nullptr, N, 1e-6f, p + ".norm", 0, t0));
+        half_t* h = alloc(rows * C);
+        if (!h) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, p + ".proj_in.weight#nhwc", p + ".proj_in.bias", C, h, C));
+        // ---- attn1
+        half_t *gm, *bt;
+        gm = W(b + ".norm1.weight"); bt = W(b + ".norm1.bias");
+        if (!gm || !bt) return u.missing_error();
+        RUN(uv_launch_layernorm(h, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+        half_t* qkv = alloc(rows * 3 * C);
+        if (!qkv) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, b + ".attn1.qkv#fused", "", 3 * C, qkv, 3 * C));
+        const bool registered = pnp_layer && pnp && pnp->registered;
+        if (registered && pnp->idx >= pnp->eta1 && pnp->idx <= pnp->eta2 * 50.f) {
+            UV_REQUIRE(B == 3, "PnP attention shift needs the three-branch batch (B=3), got B=%d", B);
+            const float beta = (0.9f - 0.1f) / (pnp->eta1 * 50.f - pnp->eta2 * 50.f) * ((float)pnp->idx - pnp->eta2 * 50.f) + 0.1f;
+            RUN(uv_launch_adain_shift(qkv, 3 * C, F, N, C, ad_ws, ad_ws + (long)F * 2 * C, pnp->alpha, beta, pnp->gamma, s));
+        }
+        AttnParams ap;
+        ap.q = qkv; ap.k = qkv + C; ap.v = qkv + 2 * C;
+        ap.ldq = ap.ldkv = 3 * C;
+        ap.o = t0; ap.ldo = C;
+        ap.src_idx = registered ? idx_pnp : idx_stock;
+        ap.nsrc = registered ? 2 : 3;
+        ap.BF = x.imgs; ap.Nq = N; ap.Nkv = N; ap.heads = heads; ap.d = d;
+        ap.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+        RUN(uv_launch_attention(ap, s));
+        free(qkv);
+        half_t* h2 = alloc(rows * C);
+        if (!h2) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2, C, h, C));
+        free(h);
+        // ---- attn2 (text)
+        gm = W(b + ".norm2.weight"); bt = W(b + ".norm2.bias");
+        if (!gm || !bt) return u.missing_error();
+        RUN(uv_launch_layernorm(h2, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+        half_t* q2 = alloc(rows * C);
+        half_t* kv = alloc((long)B * text_len * 2 * C);
+        if (!q2 || !kv) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, b + ".attn2.to_q.weight", "", C, q2, C));
+        RUN(linear(text, u.cfg.cross_attention_dim, (long)B * text_len, u.cfg.cross_attention_dim, b + ".attn2.kv#fused", "",
+                   2 * C, kv, 2 * C));
+        ap.q = q2; ap.ldq = C;
+        ap.k = kv; ap.v = kv + C; ap.ldkv = 2 * C;
+        ap.o = t0; ap.ldo = C;
+        ap.src_idx = idx_text; ap.nsrc = 1; ap.Nkv = text_len;
+        RUN(uv_launch_attention(ap, s));
+        free(q2);
+        free(kv);
+        half_t* h3 = alloc(rows * C);
+        if (!h3) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3, C, h2, C));
+        free(h2);
+        // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
+        gm = W(b + ".norm3.weight"); bt = W(b + ".norm3.bias");
+        if (!gm || !bt) return u.missing_error();
+        RUN(uv_launch_layernorm(h3, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+        half_t* mid = alloc(rows * 4 * C);
+        if (!mid) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu", 8 * C, mid, 4 * C, nullptr,
+                   0, nullptr, 1));
+        half_t* tb = W(b + ".attn_temporal.to_out.0.bias");
+        if (!tb) return u.missing_error();
+        half_t* h4 = alloc(rows * C);
+        if (!h4) return UV_ERR_STATE;
+        RUN(linear(mid, 4 * C, rows, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", C, h4, C, h3, C, tb));
+        free(mid);
+        free(h3);
+        free(t0);
+        out->imgs = x.imgs; out->H = x.H; out->W = x.W; out->C = C;
+        out->p = alloc(rows * C);
+        if (!out->p) return UV_ERR_STATE;
+        RUN(linear(h4, C, rows, C, p + ".proj_out.weight#nhwc", p + ".proj_out.bias", C, out->p, C, x.p, C));
+        free(h4);
+        return UV_OK;
+    }
+};
+
+int UNet::missing_error() {
+    uv_set_error("weight '%s' was never loaded", missing.c_str());
+    return UV_ERR_STATE;
+}
+
+int UNet::forward(const half_t* sample, float timestep, const half_t* text, int B, int F, int H, int Wd, int text_len,
+                  const univst_pnp_t* pnp, half_t* eps_out, half_t* feat_out, int ft_index, hipStream_t s) {
+    UV_REQUIRE(finalized, "forward: call univst_unet_finalize after loading weights");
+    UV_REQUIRE(B >= 1 && B <= 8 && F >= 1 && H >= 8 && Wd >= 8 && H % 8 == 0 && Wd % 8 == 0,
+               "forward: unsupported geometry B=%d F=%d H=%d W=%d (H, W multiples of 8; B <= 8)", B, F, H, Wd);
+    RUN(reserve(B, F, H, Wd));
+    missing.clear();
+    const int* boc = cfg.block_out_channels;
+    const int C0 = boc[0], TED = 4 * C0, L = cfg.layers_per_block;
+    Fwd f{*this, s, B, F, text_len, pnp};
+    f.text = text;
+    const int* tab = idx_tables[((long)B << 20) | F];
+    f.idx_stock = tab;
+    f.idx_pnp = tab + (long)B * F * 3;
+    f.idx_text = tab + (long)B * F * 5;
+    f.gn_ws = (float*)arena.alloc((size_t)uv_groupnorm_workspace_floats(B * F, cfg.norm_num_groups) * sizeof(float));
+    f.ad_ws = (float*)arena.alloc((size_t)F * 2 * boc[3] * 2 * sizeof(float) + 1024);
+    UV_REQUIRE(f.gn_ws && f.ad_ws, "forward: arena too small");
+
+    // ---- time embedding (unet_3d_condition.py:359-365)
+    half_t* tsin = f.alloc((long)B * C0);
+    half_t* e1 = f.alloc((long)B * TED);
+    f.emb = f.alloc((long)B * TED);
+    if (!tsin || !e1 || !f.emb) return UV_ERR_STATE;
+    RUN(uv_launch_timestep_embed(timestep, tsin, B, C0, cfg.flip_sin_to_cos, cfg.freq_shift, s));
+    {
+        half_t *w1 = W("time_embedding.linear_1.weight"), *b1 = W("time_embedding.linear_1.bias");
+        half_t *w2 = W("time_embedding.linear_2.weight"), *b2 = W("time_embedding.linear_2.bias");
+        if (!w1 || !b1 || !w2 || !b2) return missing_error();
+        RUN(uv_launch_linear_small(tsin, w1, b1, e1, B, TED, C0, 0, s));
+        RUN(uv_launch_linear_small(e1, w2, b2, f.emb, B, TED, TED, 1, s));
+    }
+    // ---- conv_in
+    const int CP = (cfg.in_channels + 7) / 8 * 8;
+    Act x0{f.alloc((long)B * F * H * Wd * CP), B * F, H, Wd, CP};
+    if (!x0.p) return UV_ERR_STATE;
+    RUN(uv_launch_ncfhw_to_nhwc(sample, x0.p, B, cfg.in_channels, F, H * Wd, CP, s));
+    Act x;
+    RUN(f.conv(x0, nullptr, "conv_in", C0, 9, 1, 0, nullptr, nullptr, &x));
+    f.free(x0.p);
+
+    std::vector<Act> skips;
+    skips.push_back(x);
+    // ---- down
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "down_blocks." + std::to_string(i);
+        const bool has_attn = i < 3;
+        for (int j = 0; j < L; ++j) {
+            Act y;
+            RUN(f.resblock(p + ".resnets." + std::to_string(j), x, nullptr, boc[i], &y));
+            bool x_is_skip = false;
+            for (auto& sk : skips) x_is_skip |= (sk.p == x.p);
+            if (!x_is_skip) f.free(x.p);
+            x = y;
+            if (has_attn) {
+                Act z;
+                RUN(f.transformer(p + ".attentions." + std::to_string(j), x, false, &z));
+                f.free(x.p);
+                x = z;
+            }
+            skips.push_back(x);
+        }
+        if (i != 3) {
+            Act y;
+            RUN(f.conv(x, nullptr, p + ".downsamplers.0.conv", boc[i], 9, 2, 0, nullptr, nullptr, &y));
+            x = y;
+            skips.push_back(x);
+        }
+    }
+    // ---- mid
+    {
+        Act y, z, w;
+        RUN(f.resblock("mid_block.resnets.0", x, nullptr, boc[3], &y));
+        RUN(f.transformer("mid_block.attentions.0", y, false, &z));
+        f.free(y.p);
+        RUN(f.resblock("mid_block.resnets.1", z, nullptr, boc[3], &w));
+        f.free(z.p);
+        x = w;   // previous x is skips.back(), still owned by the skip list
+    }
+    // ---- up
+    static const int pnp_layers[4][3] = {{0, 0, 0}, {0, 1, 1}, {1, 1, 1}, {1, 1, 1}};   // pnp_utils.py:104-111
+    for (int i = 0; i < 4; ++i) {
+        const std::string p = "up_blocks." + std::to_string(i);
+        const int Cout = boc[3 - i];
+        const bool has_attn = i > 0;
+        for (int j = 0; j < L + 1; ++j) {
+            Act sk = skips.back();
+            skips.pop_back();
+            Act y;
+            RUN(f.resblock(p + ".resnets." + std::to_string(j), x, &sk, Cout, &y));
+            f.free(x.p);
+            f.free(sk.p);
+            x = y;
+            if (has_attn) {
+                Act z;
+                RUN(f.transformer(p + ".attentions." + std::to_string(j), x, j < 3 && pnp_layers[i][j], &z));
+                f.free(x.p);
+                x = z;
+            }
+        }
+        if (i != 3) {
+            Act y;
+            RUN(f.conv(x, nullptr, p + ".upsamplers.0.conv", Cout, 9, 1, 1, nullptr, nullptr, &y));
+            f.free(x.p);
+            x = y;
+        }
+        if (feat_out && i == ft_index)   // sample[0].permute(1,2,3,0) == the first F*H*W NHWC rows
+            UV_HIP(hipMemcpyAsync(feat_out, x.p, (size_t)F * x.H * x.W * x.C * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+    }
+    // ---- out
+    half_t* n = f.alloc(x.rows() * x.C);
+    if (!n) return UV_ERR_STATE;
+    RUN(f.groupnorm(x, nullptr, F * x.H * x.W, cfg.norm_eps, "conv_norm_out", 1, n));
+    Act na{n, x.imgs, x.H, x.W, x.C}, y;
+    RUN(f.conv(na, nullptr, "conv_out", cfg.out_channels, 9, 1, 0, nullptr, nullptr, &y));
+    RUN(uv_launch_nhwc_to_ncfhw(y.p, cfg.out_channels, eps_out, B, cfg.out_channels, F, H * Wd, s));
+    if (!missing.empty()) return missing_error();
+    return UV_OK;
+}

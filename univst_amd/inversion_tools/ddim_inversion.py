@@ -1,0 +1,108 @@
+"""Mirror of inversion_tools/ddim_inversion.py of the reference (same function names / arguments / files
+written).  The UNet calls and the DDIM updates run in HIP kernels (univst_amd.engine)."""
+import os
+
+import torch
+
+from .. import engine
+from ..src.util import load_video_frames, save_videos_grid
+
+
+def _encode_frames(pipe, pixel_values, num_frames):
+    latents = pipe.vae.encode(pixel_values).latent_dist.sample()
+    latents = latents.view(-1, num_frames, *latents.shape[1:]).permute(0, 2, 1, 3, 4)
+    return latents * pipe.vae.config.scaling_factor
+
+
+def content_inversion_reconstruction(pipe, ddim_inv_scheduler, content_path, inversion_path, reconstruction_path, num_frames,
+                                     height, width, time_steps, weight_dtype, ft_indices=None, ft_timesteps=None, ft_path=None,
+                                     is_opt=True, reconstruct=True):
+    """ddim_inversion.py:16-42 (PNG-folder input; .mp4 needs decord which is not part of this build)."""
+    if content_path.endswith(".mp4"):
+        raise NotImplementedError(".mp4 input needs decord; extract frames to %05d.png")
+    pixel_values = load_video_frames(content_path, num_frames, image_size=(width, height)).to(weight_dtype).cuda()
+    latents = _encode_frames(pipe, pixel_values, num_frames)
+    print("inversion:")
+    z = ddim_inversion(pipe, ddim_inv_scheduler, video_latent=latents, num_inv_steps=time_steps, prompt="",
+                       inversion_path=inversion_path, ft_indices=ft_indices, ft_timesteps=ft_timesteps, ft_path=ft_path,
+                       is_opt=is_opt)[-1].to(weight_dtype)
+    if reconstruct:
+        print("reconstruction:")
+        sample = pipe.reconstruction("", latents=z, video_length=num_frames, guidance_scale=1.0).images
+        save_videos_grid(sample.permute(0, 4, 1, 2, 3).contiguous(), os.path.join(reconstruction_path, "content_video.mp4"), fps=8)
+    return z
+
+
+def style_inversion_reconstruction(pipe, ddim_inv_scheduler, style_path, inversion_path, reconstruction_path, num_frames, height,
+                                   width, time_steps, weight_dtype, ft_indices=None, ft_timesteps=None, ft_path=None,
+                                   is_opt=False, reconstruct=True):
+    """ddim_inversion.py:45-65: the style image repeated num_frames times."""
+    from ..src.util import load_image
+    import numpy as np
+    img = load_image(style_path, image_size=(width, height))
+    px = torch.from_numpy((np.array(img) / 127.5) - 1.0).permute(2, 0, 1).float()
+    pixel_values = px.unsqueeze(0).repeat(num_frames, 1, 1, 1).to(weight_dtype).cuda()
+    latents = _encode_frames(pipe, pixel_values, num_frames)
+    print("inversion:")
+    z = ddim_inversion(pipe, ddim_inv_scheduler, video_latent=latents, num_inv_steps=time_steps, prompt="",
+                       inversion_path=inversion_path, ft_indices=ft_indices, ft_timesteps=ft_timesteps, ft_path=ft_path,
+                       is_opt=is_opt)[-1].to(weight_dtype)
+    if reconstruct:
+        print("reconstruction:")
+        sample = pipe.reconstruction("", latents=z, video_length=num_frames, guidance_scale=1.0).images
+        save_videos_grid(sample.permute(0, 4, 1, 2, 3).contiguous(), os.path.join(reconstruction_path, "style_video.mp4"), fps=8)
+    return z
+
+
+@torch.no_grad()
+def ddim_inversion(pipeline, ddim_scheduler, video_latent, num_inv_steps, prompt="", inversion_path=None, ft_indices=None,
+                   ft_timesteps=None, ft_path=None, is_opt=False):
+    """ddim_inversion.py:71-84"""
+    loop = ddim_loop_plus if is_opt else ddim_loop
+    return loop(pipeline, ddim_scheduler, video_latent, num_inv_steps, prompt, inversion_path, ft_indices=ft_indices,
+                ft_timesteps=ft_timesteps, ft_path=ft_path)
+
+
+def _run(pipeline, sched, latent, n, prompt, inversion_path, easy, ft_indices, ft_timesteps, ft_path):
+    cond = init_prompt(pipeline, prompt).chunk(2)[1]
+
+    def save(k, z):
+        if inversion_path is not None:
+            torch.save(z.detach().clone(), os.path.join(inversion_path, f"ddim_latents_{k}.pt"))
+    return engine.inversion_loop(pipeline, sched, latent.cuda(), cond, n, easy, ft_indices, ft_timesteps, ft_path, save)
+
+
+@torch.no_grad()
+def ddim_loop(pipeline, ddim_scheduler, latent, num_inv_steps, prompt, inversion_path, ft_indices=None, ft_timesteps=None,
+              ft_path=None):
+    """ddim_inversion.py:87-113"""
+    return _run(pipeline, ddim_scheduler, latent, num_inv_steps, prompt, inversion_path, False, ft_indices, ft_timesteps, ft_path)
+
+
+@torch.no_grad()
+def ddim_loop_plus(pipeline, ddim_scheduler, latent, num_inv_steps, prompt, inversion_path, ft_indices=None, ft_timesteps=None,
+                   ft_path=None):
+    """ddim_inversion.py:116-167 (Easy-Inv; the 'fix' iterations are dead code upstream: num_fix_itr = 0)"""
+    return _run(pipeline, ddim_scheduler, latent, num_inv_steps, prompt, inversion_path, True, ft_indices, ft_timesteps, ft_path)
+
+
+@torch.no_grad()
+def init_prompt(pipeline, prompt):
+    """ddim_inversion.py:170-187"""
+    tok = pipeline.tokenizer
+    un = tok([""], padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
+    ue = pipeline.text_encoder(un.input_ids.to(pipeline.device))[0]
+    ti = tok([prompt], padding="max_length", max_length=tok.model_max_length, truncation=True, return_tensors="pt")
+    te = pipeline.text_encoder(ti.input_ids.to(pipeline.device))[0]
+    return torch.cat([ue, te])
+
+
+def next_step(model_output, timestep, sample, ddim_scheduler):
+    """ddim_inversion.py:190-204"""
+    return engine.next_step(model_output, timestep, sample, ddim_scheduler)
+
+
+def get_noise_pred_single(pipeline, latents, t, context, ft_indices=None, ft_timesteps=None, ft_path=None):
+    """ddim_inversion.py:207-212"""
+    return pipeline.unet(latents, t, encoder_hidden_states=context, ft_indices=ft_indices, ft_timesteps=ft_timesteps,
+                         ft_path=ft_path)["sample"]

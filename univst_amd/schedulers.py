@@ -1,0 +1,55 @@
+"""DDIMScheduler with the diffusers 0.35.1 semantics the UniVST SD path relies on (SD-v1.5
+scheduler_config.json: scaled_linear betas, steps_offset=1, leading spacing, set_alpha_to_one=False, eta=0).
+Used when ``diffusers`` is not installed; the pipeline is duck-typed and accepts the real diffusers object too
+(it only reads ``timesteps``, ``alphas_cumprod``, ``final_alpha_cumprod``, ``num_inference_steps`` and
+``config.num_train_timesteps``).  The arithmetic of ``step`` itself runs in the axpby HIP kernel
+(univst_amd.engine.ddim_step); this class only owns the schedule tables."""
+import json
+import os
+
+import numpy as np
+import torch
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class DDIMScheduler:
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 steps_offset=1, set_alpha_to_one=False, clip_sample=False, prediction_type="epsilon",
+                 timestep_spacing="leading", **unused):
+        if beta_schedule != "scaled_linear" or prediction_type != "epsilon" or timestep_spacing != "leading" or clip_sample:
+            raise NotImplementedError("only the SD-v1.5 DDIM configuration is implemented")
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                           beta_schedule=beta_schedule, steps_offset=steps_offset, set_alpha_to_one=set_alpha_to_one,
+                           clip_sample=clip_sample, prediction_type=prediction_type, timestep_spacing=timestep_spacing)
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_pretrained(cls, path=None, subfolder=None, **kw):
+        cfg = {}
+        if path is not None:
+            p = os.path.join(path, subfolder or "", "scheduler_config.json")
+            if os.path.isfile(p):
+                with open(p) as f:
+                    cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        cfg.update(kw)
+        return cls(**cfg)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts)

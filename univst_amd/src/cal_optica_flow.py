@@ -1,0 +1,70 @@
+"""Mirror of src/cal_optica_flow.py of the reference + the sliding-window block of
+stable_diffusion.py:723-751, on the GPU (csrc/warp.hip).
+
+RAFT (torchvision ``raft_large`` + weights) is third-party and is NOT re-implemented: every entry takes a
+``flow_fn(img1_u8[H,W,3], img2_u8[H,W,3]) -> float32 [H,W,2]`` callable (device tensors).
+``make_raft_flow_fn`` builds one from torchvision when it is installed (model created ONCE, not once per
+call as the reference does, cal_optica_flow.py:53-55)."""
+import torch
+
+from .. import _native
+
+
+def make_raft_flow_fn(device="cuda"):
+    from torchvision.models.optical_flow import raft_large, Raft_Large_Weights   # third-party, optional
+    model = raft_large(weights=Raft_Large_Weights.DEFAULT).to(device).eval()
+
+    @torch.no_grad()
+    def flow_fn(img1, img2):
+        a = img1.permute(2, 0, 1).float().unsqueeze(0) / 255.0
+        b = img2.permute(2, 0, 1).float().unsqueeze(0) / 255.0
+        return model(a, b)[-1].squeeze(0).permute(1, 2, 0).contiguous()
+    return flow_fn
+
+
+def warp_accumulate_(acc, key, now, fwd, bwd, threshold=1.5):
+    """acc[H,W,3] f32 += get_warp(key, now) (cal_optica_flow.py:51-99 with ref_image1=key, ref_image2=now)."""
+    H, W, _ = key.shape
+    _native.check(_native.load().univst_warp_accumulate(key.data_ptr(), now.data_ptr(), fwd.contiguous().data_ptr(),
+                                                        bwd.contiguous().data_ptr(), acc.data_ptr(), H, W, float(threshold),
+                                                        _native.stream_ptr()), "warp_accumulate")
+    return acc
+
+
+def get_warp(flow_fn, image1, image2):
+    """uint8 [H,W,3] device tensors -> warped/occlusion-composited uint8 [H,W,3]."""
+    acc = torch.zeros(*image1.shape, dtype=torch.float32, device=image1.device)
+    warp_accumulate_(acc, image1.contiguous(), image2.contiguous(), flow_fn(image1, image2), flow_fn(image2, image1))
+    return acc.to(torch.uint8)
+
+
+@torch.no_grad()
+def sliding_window_smooth(frames, flow_fn, mask01=None, r=2):
+    """stable_diffusion.py:723-751.  frames uint8 [1,3,F,H,W] (device), mask01 uint8 [F,H,W] in {0,1}
+    (1 = keep the original pixel).  Gauss-Seidel over key frames like the reference (key k sees the already
+    smoothed k-2, k-1), so frames are processed sequentially; each (key, neighbour) pair is one fused
+    occlusion + cv2-exact remap + accumulate launch."""
+    lib = _native.load()
+    b, c, F_, H, W = frames.shape
+    assert b == 1 and c == 3
+    est = frames[0].permute(1, 2, 3, 0).contiguous()            # [F,H,W,3] working copy (HWC like the reference's frames)
+    ori = est.clone()
+    n = H * W * 3
+    for key in range(F_):
+        acc = torch.zeros(H, W, 3, dtype=torch.float32, device=frames.device)
+        key_frame = est[key].clone()
+        weight = 0
+        for bias in range(-r, r + 1):
+            now = key + bias
+            if 0 <= now < F_:
+                if bias == 0:
+                    _native.check(lib.univst_accumulate_u8(est[now].data_ptr(), acc.data_ptr(), n, _native.stream_ptr()), "accumulate")
+                else:
+                    now_frame = est[now]
+                    warp_accumulate_(acc, key_frame, now_frame, flow_fn(key_frame, now_frame), flow_fn(now_frame, key_frame))
+                weight += 1
+        _native.check(lib.univst_window_store(acc.data_ptr(), float(weight), est[key].data_ptr(), n, _native.stream_ptr()), "window_store")
+    if mask01 is not None:
+        m = mask01.to(torch.bool)[..., None]
+        est = torch.where(m, ori, est)
+    return est.permute(3, 0, 1, 2).unsqueeze(0).contiguous()

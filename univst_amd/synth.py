@@ -1,0 +1,68 @@
+"""Synthetic SD-shaped weights / inputs generated directly on the GPU (bench.py, smoke): no SD checkpoint,
+VAE or CLIP exists on the target boxes, so the benchmark uses random-init weights of the SD-v1.5 architecture
+and N(0,1) latents.  The recipe mirrors oracle.unet_ref.synth_state_dict in distribution
+(fan-in scaled matrices, unit norms, reference-initialised *_temporal* layers), not bit-for-bit."""
+import math
+
+import torch
+
+SD15_UNET_CONFIG = dict(sample_size=64, in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
+                        layers_per_block=2, cross_attention_dim=768, attention_head_dim=8, norm_num_groups=32,
+                        norm_eps=1e-5)
+
+
+def build_unet(config=None, device="cuda", dtype=torch.float16, seed=33):
+    """UNetPseudo3DConditionModel with synthetic weights, materialised straight on ``device``."""
+    from .backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel
+    cfg = dict(SD15_UNET_CONFIG if config is None else config)
+    with torch.device("meta"):
+        unet = UNetPseudo3DConditionModel(**cfg)
+    unet = unet.to_empty(device=device).to(dtype)
+    synth_init_(unet, seed)
+    return unet.requires_grad_(False)
+
+
+@torch.no_grad()
+def synth_init_(unet, seed=33):
+    g = torch.Generator(device=unet.device).manual_seed(seed)
+    for name, p in unet.state_dict().items():
+        rn = lambda: torch.randn(p.shape, generator=g, device=p.device, dtype=torch.float32)
+        is_norm = (".norm" in name or name.startswith("conv_norm_out")) and p.dim() == 1
+        if "conv_temporal.weight" in name:
+            t = torch.zeros(p.shape, device=p.device)
+            c = min(p.shape[0], p.shape[1])
+            t[torch.arange(c), torch.arange(c), p.shape[2] // 2] = 1.0          # nn.init.dirac_
+        elif "conv_temporal.bias" in name or "attn_temporal.to_out.0.weight" in name:
+            t = torch.zeros(p.shape, device=p.device)
+        elif "attn_temporal.to_out.0.bias" in name:
+            t = (torch.rand(p.shape, generator=g, device=p.device) * 2 - 1) / math.sqrt(p.shape[0])
+        elif is_norm:
+            t = 1.0 + 0.1 * rn() if name.endswith("weight") else 0.05 * rn()
+        elif name.endswith(".bias"):
+            t = 0.02 * rn()
+        else:
+            fan_in = 1
+            for d in p.shape[1:]:
+                fan_in *= d
+            t = rn() / math.sqrt(fan_in)
+        p.copy_(t.to(p.dtype))
+    unet._native_dirty = True
+
+
+def synth_transfer_inputs(F=16, h=64, w=64, D=768, n=50, device="cuda", seed=1234, with_mask=False, mask_hw=512):
+    """content/style inversion trajectories (n+1 latents each), text embedding [3,77,D], optional masks."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g, device=device, dtype=torch.float32).to(torch.float16)
+    content = [rn(1, 4, F, h, w) for _ in range(n + 1)]
+    style = [(rn(1, 4, 1, h, w).float().expand(1, 4, F, h, w) + 1e-3 * rn(1, 4, F, h, w).float()).to(torch.float16).contiguous()
+             for _ in range(n + 1)]
+    text = rn(1, 77, D).expand(3, -1, -1).contiguous()
+    mask = None
+    if with_mask:
+        yy, xx = torch.meshgrid(torch.arange(mask_hw, device=device), torch.arange(mask_hw, device=device), indexing="ij")
+        ms = []
+        for f in range(F):
+            cx = mask_hw / 2 - 4 * F / 2 + 4 * f
+            ms.append(((xx - cx) ** 2 + (yy - mask_hw / 2) ** 2 <= (mask_hw / 4) ** 2).to(torch.uint8))
+        mask = torch.stack(ms)[None]
+    return content, style, text, mask
