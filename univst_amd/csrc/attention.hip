@@ -18,16 +18,24 @@
 namespace {
 
 constexpr int KT = 64;   // keys per LDS tile
+constexpr float DEFER = 8.f;   // deferred-rescale threshold in the exp2 domain (P <= 2^8 between rescales)
+
+typedef __fp16 fh2 __attribute__((ext_vector_type(2)));
 
 template <int DPAD, int DV16, int QB>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+__device__ __forceinline__ void attn_body(const AttnParams& p) {
     constexpr int KSTR = lds_stride_bytes(DPAD * 2) / 2;
     constexpr int DV = DV16 * 16;
     constexpr int VSTR = lds_stride_bytes(DV * 2) / 2;
     constexpr int KS = DPAD / 32;
-    __shared__ __attribute__((aligned(16))) half_t smem[KT * KSTR + KT * VSTR];
-    half_t* Ks = smem;
-    half_t* Vs = smem + KT * KSTR;
+    constexpr int KCH = DPAD / 8, VCH = DV / 8;
+    constexpr int NKL = (KT * KCH + 255) / 256, NVL = (KT * VCH + 255) / 256;   // staging loads per thread
+    constexpr int TILE = KT * KSTR + KT * VSTR;
+    constexpr bool DBUF = (2 * TILE * 2) <= 48 * 1024;     // double-buffer when it keeps >= 3 blocks per CU
+    // ONES: head_dim 40 leaves V columns 40..47 of the 48-wide V tile unused -> column 40 holds 1.0 so the PV MFMA
+    // accumulates the softmax denominator (from the SAME fp16-rounded P that multiplies V) in a spare O^T row.
+    constexpr bool ONES = (DV16 == 3);
+    __shared__ __attribute__((aligned(16))) half_t smem[(DBUF ? 2 : 1) * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 
     f4 o[DV16][QB];
-    float mrun[QB], lrun[QB];
+    float mrun[QB], lrun[QB];      // running max in RAW score units; lrun unused when ONES
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         mrun[qb] = -INFINITY;
@@ -63,101 +71,165 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         for (int dv = 0; dv < DV16; ++dv) o[dv][qb] = f4{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int s = 0; s < p.nsrc; ++s) {
+    const int ntile = (p.Nkv + KT - 1) / KT;
+    const int T = p.nsrc * ntile;
+    h8 kr[NKL], vr[NVL];
+    auto load_tile = [&](int tt) {        // global -> registers (flies under the MFMAs of the previous tile)
+        const int s = tt / ntile, t0 = (tt - s * ntile) * KT;
         const long src = p.src_idx[bf * p.nsrc + s];
-        for (int t0 = 0; t0 < p.Nkv; t0 += KT) {
-            __syncthreads();
-            // ---- stage K tile [64][DPAD] and V tile [64][DV] (zero-filled beyond d / Nkv)
-            constexpr int KCH = DPAD / 8;
-            for (int idx = tid; idx < KT * KCH; idx += 256) {
-                const int row = idx / KCH, ch = idx - row * KCH;
-                const bool ok = (t0 + row < p.Nkv) && (ch * 8 < d);
-                h8 v = ok ? *reinterpret_cast<const h8*>(p.k + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
-                *reinterpret_cast<h8*>(&Ks[row * KSTR + ch * 8]) = v;
-            }
-            constexpr int VCH = DV / 8;
-            for (int idx = tid; idx < KT * VCH; idx += 256) {
-                const int row = idx / VCH, ch = idx - row * VCH;
-                const bool ok = (t0 + row < p.Nkv) && (ch * 8 < d);
-                h8 v = ok ? *reinterpret_cast<const h8*>(p.v + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
-                *reinterpret_cast<h8*>(&Vs[row * VSTR + ch * 8]) = v;
-            }
-            __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / KCH, ch = idx - row * KCH;
+            const bool ok = (idx < KT * KCH) && (t0 + row < p.Nkv) && (ch * 8 < d);
+            kr[i] = ok ? *reinterpret_cast<const h8*>(p.k + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / VCH, ch = idx - row * VCH;
+            const bool rok = (idx < KT * VCH) && (t0 + row < p.Nkv);
+            h8 v = (rok && ch * 8 < d) ? *reinterpret_cast<const h8*>(p.v + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
+            if (ONES && rok && ch * 8 == d) v[0] = (half_t)1.f;
+            vr[i] = v;
+        }
+    };
+    auto store_tile = [&](half_t* Ks, half_t* Vs) {
+#pragma unroll
+        for (int i = 0; i < NKL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / KCH, ch = idx - row * KCH;
+            if (idx < KT * KCH) *reinterpret_cast<h8*>(&Ks[row * KSTR + ch * 8]) = kr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / VCH, ch = idx - row * VCH;
+            if (idx < KT * VCH) *reinterpret_cast<h8*>(&Vs[row * VSTR + ch * 8]) = vr[i];
+        }
+    };
 
-            // ---- S^T = K Q^T
-            f4 sc[4][QB];
+    const float c = p.scale_log2e;
+    load_tile(0);
+    store_tile(smem, smem + KT * KSTR);
+    __syncthreads();
+
+    for (int tt = 0; tt < T; ++tt) {
+        half_t* Ks = smem + (DBUF ? (tt & 1) * TILE : 0);
+        half_t* Vs = Ks + KT * KSTR;
+        if (tt + 1 < T) load_tile(tt + 1);
+        const int t0 = (tt % ntile) * KT;
+
+        // ---- S^T = K Q^T
+        f4 sc[4][QB];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    h8 a = *reinterpret_cast<const h8*>(&Ks[(kb * 16 + l15) * KSTR + ks * 32 + g * 8]);
+            for (int kb = 0; kb < 4; ++kb) {
+                h8 a = *reinterpret_cast<const h8*>(&Ks[(kb * 16 + l15) * KSTR + ks * 32 + g * 8]);
 #pragma unroll
-                    for (int qb = 0; qb < QB; ++qb)
-                        sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qb][ks], sc[kb][qb], 0, 0, 0);
-                }
+                for (int qb = 0; qb < QB; ++qb)
+                    sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qb][ks], sc[kb][qb], 0, 0, 0);
             }
-            const bool tail = t0 + KT > p.Nkv;
+        }
+        if (t0 + KT > p.Nkv) {            // tail tile: mask keys beyond Nkv (block-uniform branch)
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                // scale, mask, row max (lane-local over 16 values, then across the 4 lane groups)
-                float mx = -INFINITY;
+            for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = sc[kb][qb][r] * p.scale_log2e;
-                        if (tail && (t0 + kb * 16 + g * 4 + r >= p.Nkv)) v = -INFINITY;
-                        sc[kb][qb][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    for (int r = 0; r < 4; ++r)
+                        if (t0 + kb * 16 + g * 4 + r >= p.Nkv) sc[kb][qb][r] = -INFINITY;
+        }
+        h8 pb[QB][2];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            // row max over raw scores (lane-local over 16 values, then across the 4 lane groups)
+            float mx = fmaxf(fmaxf(sc[0][qb][0], sc[0][qb][1]), fmaxf(sc[0][qb][2], sc[0][qb][3]));
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb)
+                mx = fmaxf(mx, fmaxf(fmaxf(sc[kb][qb][0], sc[kb][qb][1]), fmaxf(sc[kb][qb][2], sc[kb][qb][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // deferred rescale (guide T13): keep the old running max while the new one is at most 2^DEFER larger in
+            // the exp2 domain; P is then bounded by 2^DEFER (fp16 keeps full relative precision there) and the O^T
+            // rescale + its accumulator traffic is skipped for the whole wave.
+            float alpha = 1.f;
+            if (__builtin_amdgcn_ballot_w64((mx - mrun[qb]) * c > DEFER) != 0) {
                 const float mnew = fmaxf(mrun[qb], mx);
-                const float alpha = __builtin_amdgcn_exp2f(mrun[qb] - mnew);
+                alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * c);
                 mrun[qb] = mnew;
-                float rs = 0.f;
-                h8 pb[2];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float e = __builtin_amdgcn_exp2f(sc[kb][qb][r] - mnew);
-                        rs += e;
-                        pb[kb >> 1][(kb & 1) * 4 + r] = (half_t)e;
-                    }
-                lrun[qb] = lrun[qb] * alpha + rs;
 #pragma unroll
                 for (int dv = 0; dv < DV16; ++dv) {
                     o[dv][qb][0] *= alpha; o[dv][qb][1] *= alpha; o[dv][qb][2] *= alpha; o[dv][qb][3] *= alpha;
                 }
-                // ---- O^T += V^T P^T  (two 32-key chunks)
+                if (!ONES) lrun[qb] *= alpha;
+            }
+            const float mc = -mrun[qb] * c;
+            if (ONES) {
+                union { fh2 h[4]; h8 v; } u0, u1;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-#pragma unroll
-                    for (int dv = 0; dv < DV16; ++dv) {
-                        const half_t* vp = &Vs[(c * 32 + g * 4 + (l15 >> 2)) * VSTR + dv * 16 + (l15 & 3) * 4];
-                        fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
-                        fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * VSTR));
-                        h8 a;
-                        a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
-                        a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
-                        o[dv][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[c], o[dv][qb], 0, 0, 0);
-                    }
+                for (int kb = 0; kb < 4; ++kb) {
+                    float e0 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][0], c, mc));
+                    float e1 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][1], c, mc));
+                    float e2 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][2], c, mc));
+                    float e3 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][3], c, mc));
+                    fh2 lo = __builtin_amdgcn_cvt_pkrtz(e0, e1), hi = __builtin_amdgcn_cvt_pkrtz(e2, e3);
+                    if (kb < 2) { u0.h[(kb & 1) * 2] = lo; u0.h[(kb & 1) * 2 + 1] = hi; }
+                    else { u1.h[(kb & 1) * 2] = lo; u1.h[(kb & 1) * 2 + 1] = hi; }
                 }
+                pb[qb][0] = u0.v;
+                pb[qb][1] = u1.v;
+            } else {
+                float rs = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float e = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][r], c, mc));
+                        rs += e;
+                        pb[qb][kb >> 1][(kb & 1) * 4 + r] = (half_t)e;
+                    }
+                lrun[qb] += rs;
             }
         }
+        // ---- O^T += V^T P^T  (two 32-key chunks; V^T fragments shared by the QB query blocks)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+            for (int dv = 0; dv < DV16; ++dv) {
+                const half_t* vp = &Vs[(cc * 32 + g * 4 + (l15 >> 2)) * VSTR + dv * 16 + (l15 & 3) * 4];
+                fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
+                fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * VSTR));
+                h8 a;
+                a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
+                a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb)
+                    o[dv][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb[qb][cc], o[dv][qb], 0, 0, 0);
+            }
+        }
+        if (!DBUF) __syncthreads();      // everyone finished reading the single buffer
+        if (tt + 1 < T) store_tile(smem + (DBUF ? ((tt + 1) & 1) * TILE : 0), smem + (DBUF ? ((tt + 1) & 1) * TILE : 0) + KT * KSTR);
+        __syncthreads();
     }
 
     // ---- finalize: O^T[d = dv*16 + g*4 + r][q = l15] / l
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        float l = lrun[qb];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if (ONES) {
+            // denominator sits in O^T row d (= 40): register (d%16)%4 of lane group (d%16)/4, dv = d/16
+            l = __shfl(o[DV16 - 1][qb][0], 32 + l15, 64);
+        } else {
+            l = lrun[qb];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+        }
         const float inv = 1.f / l;
         const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
@@ -173,6 +245,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             }
         }
     }
+}
+
+template <int DPAD, int DV16, int QB>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    attn_body<DPAD, DV16, QB>(p);
+}
+// same body, register budget capped for 3 waves per SIMD (the small-head-dim kernels are VALU/latency bound:
+// one more resident wave per SIMD hides the softmax behind another wave's MFMAs)
+template <int DPAD, int DV16, int QB>
+__global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
+    attn_body<DPAD, DV16, QB>(p);
 }
 
 // lane l of a 64-lane wave reports what ds_read_b64_tr_b16 returned for a known LDS image (bring-up aid).
@@ -191,7 +274,8 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     const int QB = p.Nq >= 512 ? 2 : 1;
     const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
     dim3 grid(nqb * p.heads * p.BF), block(256);
-    if (QB == 2) hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2>), grid, block, 0, stream, p);
+    if (QB == 2 && DPAD <= 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2>), grid, block, 0, stream, p);
+    else if (QB == 2) hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1>), grid, block, 0, stream, p);
     UV_LAUNCH_CHECK();
     return UV_OK;
