@@ -74,6 +74,39 @@ def test_linear_geglu(nat):
     close(nat.linear(x, w[idx].contiguous(), bias=b[idx].contiguous(), geglu=True), ref)
 
 
+def test_linear_big_tile_path(nat):
+    """shapes that dispatch to the 256x320 GLDS kernel (>= 512 tiles), incl. M tail, K tail, bias+residual, GEGLU."""
+    M = 131072 + 77
+    for N, K in ((320, 320), (640, 72)):
+        x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+        b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+        close(nat.linear(x, w, bias=b, residual=r), x.float() @ w.float().T + b.float() + r.float())
+    C = 80
+    x, w, b = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=1 / 8), rnd(8 * C, seed=3)
+    h = x.float() @ w.float().T + b.float()
+    a, gate = h.chunk(2, dim=-1)
+    idx = []
+    for q in range(4 * C // 16):
+        idx += list(range(16 * q, 16 * q + 16)) + list(range(4 * C + 16 * q, 4 * C + 16 * q + 16))
+    idx = torch.tensor(idx).cuda()
+    close(nat.linear(x, w[idx].contiguous(), bias=b[idx].contiguous(), geglu=True), a * F.gelu(gate))
+
+
+def test_conv_big_tile_path(nat):
+    imgs, C1, C2, Co, H = 48, 32, 16, 320, 56        # 150528 output rows -> 588 tiles of 256x320
+    x1, x2 = rnd(imgs, C1, H, H, seed=1), rnd(imgs, C2, H, H, seed=2)
+    w = rnd(Co, C1 + C2, 3, 3, seed=3, scale=0.05)
+    b, rb, res = rnd(Co, seed=4), rnd(3, Co, seed=5), rnd(imgs, Co, H, H, seed=6)
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), w.float(), b.float(), padding=1)
+    ref = ref + rb.float().repeat_interleave(16, 0)[:, :, None, None] + res.float()
+    got = nat.conv_nhwc(nhwc(x1), conv_w(w), bias=b, x2=nhwc(x2), rowbias=rb, rows_per_rowbias=16 * H * H, residual=nhwc(res))
+    close(got, nhwc(ref))
+    x = rnd(imgs, 32, 32, 32, seed=7)
+    w = rnd(Co, 32, 3, 3, seed=8, scale=0.06)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1)
+    close(nat.conv_nhwc(nhwc(x), conv_w(w), bias=b, upsample=True), nhwc(ref))
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 

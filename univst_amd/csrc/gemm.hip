@@ -20,20 +20,105 @@
 // proj_out), attention.py:375-377,425 + pnp_utils.py:39-43,97 (to_q/k/v/out), diffusers FeedForward/GEGLU,
 // diffusers Attention projections, unet_3d_blocks.py:523,618 (torch.cat skip), resnet.py:145 (nearest x2).
 #include "common.h"
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BK = 64;
-constexpr int LDSH = lds_stride_bytes(BK * 2) / 2;   // 80 halfs
+// source of every out-of-range / padding 16-byte piece of the GLDS path (LDS-DMA cannot write immediates)
+__device__ __attribute__((aligned(256))) half_t uv_zero_page[128];
 
-template <int NF, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+// Epilogue for ONE output row m: col[i][r] is output channel nb + i*16 + g*4 + r.  bias / per-branch row bias /
+// residual / second bias (added after fp16 rounding) / GEGLU on interleaved [16 x | 16 gate] channel blocks.
+template <int NF>
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 (&col)[NF], int m, int nb, int g) {
+    if (m >= p.M) return;
+    const half_t* rbias = p.rowbias ? p.rowbias + (long)(m / p.rows_per_rb) * p.N : nullptr;
+    if (p.geglu) {
+        if constexpr (NF % 2 == 0) {
+#pragma unroll
+            for (int i = 0; i < NF; i += 2) {
+                const int nx = nb + i * 16 + g * 4;        // x rows (permuted weight)
+                const int ng = nx + 16;                     // gate rows
+                if (ng >= p.N) continue;
+                const int no = nb / 2 + (i / 2) * 16 + g * 4;
+                h4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float xv = col[i][r] + (p.bias ? (float)p.bias[nx + r] : 0.f);
+                    float gv = col[i + 1][r] + (p.bias ? (float)p.bias[ng + r] : 0.f);
+                    o[r] = (half_t)(xv * gelu_erf_f(gv));
+                }
+                *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + no) = o;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int n = nb + i * 16 + g * 4;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = col[i][r];
+        if (n + 3 < p.N) {
+            if (p.bias) {
+                h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+            }
+            if (rbias) {
+                h4 bv = *reinterpret_cast<const h4*>(rbias + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
+            }
+            if (p.R) {
+                h4 rv = *reinterpret_cast<const h4*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+            h4 o;
+            if (p.bias2) {
+                h4 bv = *reinterpret_cast<const h4*>(p.bias2 + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)v[r] + (float)bv[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            }
+            *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + n) = o;
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                float t = v[r];
+                if (p.bias) t += (float)p.bias[n + r];
+                if (rbias) t += (float)rbias[n + r];
+                if (p.R) t += (float)p.R[(long)m * p.ldr + n + r];
+                half_t o = (half_t)t;
+                if (p.bias2) o = (half_t)((float)o + (float)p.bias2[n + r]);
+                p.Y[(long)m * p.ldy + n + r] = o;
+            }
+        }
+    }
+}
+
+constexpr int BM = 128;
+
+// BK: k extent of one LDS tile (32 or 64).  DBUF: two LDS buffers -> one barrier per k tile, the next tile's global
+// loads stay in flight under the MFMAs and are written to the other buffer right after them.
+template <int NF, int MODE, int BK, bool DBUF, int OCC = 2, int ABL = 0, bool GLDS = false>
+__global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
     constexpr int BN = NF * 32;
-    __shared__ __attribute__((aligned(16))) half_t smem[(BM + BN) * LDSH];
-    half_t* Xs = smem;
-    half_t* Ws = smem + BM * LDSH;
+    // register-staged path: rows padded (80 halfs for BK 64 / 48 for BK 32) -> conflict-free b128 reads.
+    // GLDS path: global_load_lds writes lane-linear 16-byte pieces, so rows are UNPADDED 128 B and the 16-byte chunk
+    // index is XOR-swizzled with (row & 7) — applied to the per-lane SOURCE address and to the fragment reads.
+    constexpr int LDSH = GLDS ? BK : lds_stride_bytes(BK * 2) / 2;
+    constexpr int CPR = BK / 8;                            // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;                         // rows staged per pass
+    constexpr int XL = BM / RPP, WL = (BN + RPP - 1) / RPP;   // staging loads per thread
+    constexpr int TILE = (BM + BN) * LDSH;
+    static_assert(!GLDS || BK == 64, "GLDS path is written for BK = 64");
+    __shared__ __attribute__((aligned(16))) half_t smem[((DBUF || GLDS) ? 2 : 1) * TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -46,13 +131,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- per-thread staging geometry: chunk kc (8 halfs) of rows rb + 32*i
-    const int kc = tid & 7, rb = tid >> 3;
-    const half_t* xptr[4];
-    int x_iy0[4], x_ix0[4], x_img[4];
-    bool x_ok[4];
+    const int rb = tid / CPR;
+    const int kc = GLDS ? ((tid % CPR) ^ (rb & 7)) : (tid % CPR);     // logical 16-byte chunk this lane stages
+    const half_t* xptr[XL];
+    int x_iy0[XL], x_ix0[XL], x_img[XL];
+    bool x_ok[XL];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + rb + 32 * i;
+    for (int i = 0; i < XL; ++i) {
+        int m = m0 + rb + RPP * i;
         x_ok[i] = m < p.M;
         if (MODE == 0) {
             xptr[i] = p.X + (long)m * p.ldx + kc * 8;
@@ -66,12 +152,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             x_img[i] = img * p.Hs;
         }
     }
-    const half_t* wptr[NF];
-    bool w_ok[NF];
+    const half_t* wptr[WL];
+    bool w_ok[WL];
 #pragma unroll
-    for (int i = 0; i < NF; ++i) {
-        int n = n0 + rb + 32 * i;
-        w_ok[i] = n < p.N;
+    for (int i = 0; i < WL; ++i) {
+        int n = n0 + rb + RPP * i;
+        w_ok[i] = n < p.N && (rb + RPP * i) < BN;
         wptr[i] = p.W + (long)n * p.K + kc * 8;
     }
     const int Cin = p.C1 + p.C2;
@@ -80,15 +166,221 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         while (cc >= Cin) { cc -= Cin; ++tap; }
     }
 
-    h8 xr[4], wr[NF];
+    h8 xr[XL], wr[WL];
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     auto load_tile = [&](int k0) {
         const bool kok = (k0 + kc * 8) < p.K;
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < XL; ++i)
                 xr[i] = (x_ok[i] && kok) ? *reinterpret_cast<const h8*>(xptr[i] + k0) : zero8;
+        } else {
+            const int ky = (p.taps == 9) ? tap / 3 : 0;
+            const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
+            const int He = p.Hs << p.up, We = p.Ws << p.up;
+            const bool src2 = cc >= p.C1;
+            const half_t* base = src2 ? p.X2 : p.X;
+            const int cs = src2 ? p.C2 : p.C1;
+            const int co = src2 ? cc - p.C1 : cc;
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+                bool ok = x_ok[i] && kok && iy >= 0 && iy < He && ix >= 0 && ix < We;
+                long pix = (long)(x_img[i] + (iy >> p.up)) * p.Ws + (ix >> p.up);
+                xr[i] = ok ? *reinterpret_cast<const h8*>(base + pix * cs + co) : zero8;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            wr[i] = (w_ok[i] && kok) ? *reinterpret_cast<const h8*>(wptr[i] + k0) : zero8;
+    };
+    auto advance_k = [&]() {
+        if (MODE == 1) {
+            cc += BK;
+            while (cc >= Cin) { cc -= Cin; ++tap; }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        half_t* Xs = smem + buf * TILE;
+        half_t* Ws = Xs + BM * LDSH;
+#pragma unroll
+        for (int i = 0; i < XL; ++i)
+            *reinterpret_cast<h8*>(&Xs[(rb + RPP * i) * LDSH + kc * 8]) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WL; ++i)
+            if ((BN % RPP == 0) || (rb + RPP * i) < BN) *reinterpret_cast<h8*>(&Ws[(rb + RPP * i) * LDSH + kc * 8]) = wr[i];
+    };
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto glds16 = [&](const half_t* src, half_t* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto issue_tile = [&](int k0, int buf) {      // GLDS: global -> LDS directly (no VGPR round trip, no ds_write)
+        half_t* Xd = smem + buf * TILE + wave_u * 8 * LDSH;
+        half_t* Wd = Xd + BM * LDSH;
+        const bool kok = (k0 + kc * 8) < p.K;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < XL; ++i) glds16((x_ok[i] && kok) ? xptr[i] + k0 : uv_zero_page, Xd + RPP * i * LDSH);
+        } else {
+            const int ky = (p.taps == 9) ? tap / 3 : 0;
+            const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
+            const int He = p.Hs << p.up, We = p.Ws << p.up;
+            const bool src2 = cc >= p.C1;
+            const half_t* base = src2 ? p.X2 : p.X;
+            const int cs = src2 ? p.C2 : p.C1;
+            const int co = src2 ? cc - p.C1 : cc;
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
+                bool ok = x_ok[i] && kok && iy >= 0 && iy < He && ix >= 0 && ix < We;
+                long pix = (long)(x_img[i] + (iy >> p.up)) * p.Ws + (ix >> p.up);
+                glds16(ok ? base + pix * cs + co : uv_zero_page, Xd + RPP * i * LDSH);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WL; ++i) glds16((w_ok[i] && kok) ? wptr[i] + k0 : uv_zero_page, Wd + RPP * i * LDSH);
+    };
+
+    f4 acc[NF][4];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    if (GLDS) {
+        issue_tile(0, 0);
+        advance_k();
+    } else {
+        load_tile(0);
+        advance_k();
+        store_tile(0);
+        __syncthreads();
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const half_t* Xs = smem + ((DBUF || GLDS) ? (kt & 1) * TILE : 0);
+        const half_t* Ws = Xs + BM * LDSH;
+        if (GLDS) {
+            __syncthreads();              // (vmcnt(0) + barrier) tile kt landed for every wave; buffer (kt+1)&1 is free
+            if (kt + 1 < nk) {            // next tile's DMA flies under this tile's MFMAs
+                issue_tile((kt + 1) * BK, (kt + 1) & 1);
+                advance_k();
+            }
+        } else if (kt + 1 < nk && ABL != 2 && ABL != 3) {                 // next tile's global loads fly under this tile's MFMAs
+            load_tile((kt + 1) * BK);
+            advance_k();
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            h8 a[NF], b[4];
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+                a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * NF * 16 + i * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                b[j] = *reinterpret_cast<const h8*>(&Xs[(wm * 64 + j * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
+#pragma unroll
+            for (int i = 0; i < NF; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (GLDS) {
+        } else if (DBUF) {
+            if (kt + 1 < nk) store_tile((kt + 1) & 1);
+            __syncthreads();
+        } else {
+            if (ABL != 4) __syncthreads();
+            if (kt + 1 < nk && ABL != 1 && ABL != 3 && ABL != 4) {
+                store_tile(0);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds rows n = nb + g*4 + r (r<4) of column m = mb + l15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f4 col[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
+        gemm_epilogue_row<NF>(p, col, m0 + wm * 64 + j * 16 + l15, n0 + wn * NF * 16, g);
+    }
+}
+
+
+// ----------------------------------------------------------------------------------------------------------------
+// Large-M kernel: 256 x 320 output tile, 8 waves as 4(m) x 2(n), each wave 64(m) x 160(n) = 4 x 10 fragments
+// (160 fp32 accumulators).  Every SD-v1.5 layer width is a multiple of 320, so there is no tile waste; the
+// operand traffic per flop is 2.2x lower than the 128x128 kernel, which is what lifts the L2-bandwidth ceiling
+// those tiles sit on.  Staging is global_load_lds only (two 72 KB LDS buffers, unpadded 128 B
+// rows, XOR-swizzled chunks), one barrier per 64-wide k tile, 80 MFMAs per wave between barriers.
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
+    constexpr int NF = 10, BMB = 256, BNB = 320, BK = 64, LDSH = 64;
+    constexpr int TILE = (BMB + BNB) * LDSH;                 // halfs per buffer (72 KB)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nt_n = (p.N + BNB - 1) / BNB;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % nt_n, tm = lid / nt_n;
+    const int m0 = tm * BMB, n0 = tn * BNB;
+
+    const int rb = tid >> 3;                                  // 0..63
+    const int kc = (tid & 7) ^ (rb & 7);                      // logical chunk staged by this lane
+    unsigned xoff[4];
+    int x_iy0[4], x_ix0[4], x_img[4];
+    bool x_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + rb + 64 * i;
+        x_ok[i] = m < p.M;
+        if (MODE == 0) {
+            xoff[i] = (unsigned)((long)m * p.ldx + kc * 8);
+        } else {
+            int hw = p.Ho * p.Wo;
+            int img = m / hw, rem = m - img * hw;
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            int pad = (p.taps == 9) ? 1 : 0;
+            x_iy0[i] = oy * p.stride - pad;
+            x_ix0[i] = ox * p.stride - pad;
+            x_img[i] = img * p.Hs;
+        }
+    }
+    unsigned woff[5];
+    bool w_ok[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        int n = n0 + rb + 64 * i;
+        w_ok[i] = n < p.N;
+        woff[i] = (unsigned)((long)n * p.K + kc * 8);
+    }
+    const int Cin = p.C1 + p.C2;
+    int tap = 0, cc = kc * 8;
+    if (MODE == 1) {
+        while (cc >= Cin) { cc -= Cin; ++tap; }
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const half_t* zp = uv_zero_page;
+    auto glds16 = [&](const half_t* src, half_t* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto issue_tile = [&](int k0, int buf) {
+        half_t* Xd = smem + buf * TILE + wave_u * 8 * LDSH;
+        half_t* Wd = Xd + BMB * LDSH;
+        const bool kok = (k0 + kc * 8) < p.K;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) glds16((x_ok[i] && kok) ? p.X + xoff[i] + k0 : zp, Xd + 64 * i * LDSH);
         } else {
             const int ky = (p.taps == 9) ? tap / 3 : 0;
             const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
@@ -102,26 +394,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
                 bool ok = x_ok[i] && kok && iy >= 0 && iy < He && ix >= 0 && ix < We;
                 long pix = (long)(x_img[i] + (iy >> p.up)) * p.Ws + (ix >> p.up);
-                xr[i] = ok ? *reinterpret_cast<const h8*>(base + pix * cs + co) : zero8;
+                glds16(ok ? base + pix * cs + co : zp, Xd + 64 * i * LDSH);
             }
         }
 #pragma unroll
-        for (int i = 0; i < NF; ++i)
-            wr[i] = (w_ok[i] && kok) ? *reinterpret_cast<const h8*>(wptr[i] + k0) : zero8;
-    };
-    auto advance_k = [&]() {
+        for (int i = 0; i < 5; ++i) glds16((w_ok[i] && kok) ? p.W + woff[i] + k0 : zp, Wd + 64 * i * LDSH);
         if (MODE == 1) {
             cc += BK;
             while (cc >= Cin) { cc -= Cin; ++tap; }
         }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<h8*>(&Xs[(rb + 32 * i) * LDSH + kc * 8]) = xr[i];
-#pragma unroll
-        for (int i = 0; i < NF; ++i)
-            *reinterpret_cast<h8*>(&Ws[(rb + 32 * i) * LDSH + kc * 8]) = wr[i];
     };
 
     f4 acc[NF][4];
@@ -131,109 +412,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    advance_k();
-    store_tile();
-    __syncthreads();
-
+    issue_tile(0, 0);
+    const int sw = l15 & 7;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) {                 // next tile's global loads fly under this tile's MFMAs
-            load_tile((kt + 1) * BK);
-            advance_k();
-        }
+        __syncthreads();                  // vmcnt(0) + barrier: tile kt landed everywhere, buffer (kt+1)&1 is free
+        if (kt + 1 < nk) issue_tile((kt + 1) * BK, (kt + 1) & 1);
+        const half_t* Xs = smem + (kt & 1) * TILE;
+        const half_t* Ws = Xs + BMB * LDSH;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            h8 a[NF], b[4];
+            const int ch = ((ks * 4 + g) ^ sw) * 8;
+            h8 a[NF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
-                a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * NF * 16 + i * 16 + l15) * LDSH + ks * 32 + g * 8]);
+            for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * 160 + i * 16 + l15) * LDSH + ch]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = *reinterpret_cast<const h8*>(&Xs[(wm * 64 + j * 16 + l15) * LDSH + ks * 32 + g * 8]);
+            for (int j = 0; j < 4; ++j) {
+                h8 b = *reinterpret_cast<const h8*>(&Xs[(wm * 64 + j * 16 + l15) * LDSH + ch]);
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-        if (kt + 1 < nk) {
-            store_tile();
-            __syncthreads();
+                for (int i = 0; i < NF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][j], 0, 0, 0);
+            }
         }
     }
-
-    // ---- epilogue: lane holds rows n = nb + g*4 + r (r<4) of column m = mb + l15
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + l15;
-        if (m >= p.M) continue;
-        const half_t* rbias = p.rowbias ? p.rowbias + (long)(m / p.rows_per_rb) * p.N : nullptr;
-        if (p.geglu) {
-            if constexpr (NF % 2 == 0) {
+        f4 col[NF];
 #pragma unroll
-                for (int i = 0; i < NF; i += 2) {
-                    const int nx = n0 + wn * NF * 16 + i * 16 + g * 4;        // x rows (permuted weight)
-                    const int ng = nx + 16;                                    // gate rows
-                    if (ng >= p.N) continue;
-                    const int no = (n0 + wn * NF * 16) / 2 + (i / 2) * 16 + g * 4;
-                    h4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float xv = acc[i][j][r] + (p.bias ? (float)p.bias[nx + r] : 0.f);
-                        float gv = acc[i + 1][j][r] + (p.bias ? (float)p.bias[ng + r] : 0.f);
-                        o[r] = (half_t)(xv * gelu_erf_f(gv));
-                    }
-                    *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + no) = o;
-                }
-            }
-            continue;
-        }
-#pragma unroll
-        for (int i = 0; i < NF; ++i) {
-            const int n = n0 + wn * NF * 16 + i * 16 + g * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-            if (n + 3 < p.N) {
-                if (p.bias) {
-                    h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
-                }
-                if (rbias) {
-                    h4 bv = *reinterpret_cast<const h4*>(rbias + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
-                }
-                if (p.R) {
-                    h4 rv = *reinterpret_cast<const h4*>(p.R + (long)m * p.ldr + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                h4 o;
-                if (p.bias2) {
-                    h4 bv = *reinterpret_cast<const h4*>(p.bias2 + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)v[r] + (float)bv[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                }
-                *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + n) = o;
-            } else {
-                for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                    float t = v[r];
-                    if (p.bias) t += (float)p.bias[n + r];
-                    if (rbias) t += (float)rbias[n + r];
-                    if (p.R) t += (float)p.R[(long)m * p.ldr + n + r];
-                    half_t o = (half_t)t;
-                    if (p.bias2) o = (half_t)((float)o + (float)p.bias2[n + r]);
-                    p.Y[(long)m * p.ldy + n + r] = o;
-                }
-            }
-        }
+        for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
+        gemm_epilogue_row<NF>(p, col, m0 + wm * 64 + j * 16 + l15, n0 + wn * 160, g);
     }
 }
 
@@ -282,20 +487,59 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         UV_REQUIRE(p.taps == 1 || p.taps == 9, "conv: taps=%d", p.taps);
         UV_REQUIRE(p.K == p.taps * (p.C1 + p.C2), "conv: K=%d != taps*(C1+C2)", p.K);
     }
-    bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0);
+    static const int variant0 = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
+    {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
+        static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
+        const long nblk = (long)((p.M + 255) / 256) * (p.N / 320);
+        const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
+        if (!nobig && p.N % 320 == 0 && nblk >= 512 && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
+            uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
+                          2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
+            if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)nblk), dim3(512), 0, stream, p);
+            else hipLaunchKernelGGL((gemm_big_kernel<1>), dim3((unsigned)nblk), dim3(512), 0, stream, p);
+            uv_prof_end(stream);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0) && (variant0 < 3 || variant0 == 5);
     int BN = nf5 ? 160 : 128;
     int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
     dim3 grid(nt), block(256);
+    static const int variant = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
                   2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
-    if (mode == 0) {
-        if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<4, 0>), grid, block, 0, stream, p);
-    } else {
-        if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<4, 1>), grid, block, 0, stream, p);
-    }
+#define UV_GEMM_LAUNCH(BK_, DB_)                                                                      \
+    do {                                                                                              \
+        if (mode == 0) {                                                                              \
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, BK_, DB_>), grid, block, 0, stream, p);    \
+            else hipLaunchKernelGGL((gemm_kernel<4, 0, BK_, DB_>), grid, block, 0, stream, p);        \
+        } else {                                                                                      \
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, BK_, DB_>), grid, block, 0, stream, p);    \
+            else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_>), grid, block, 0, stream, p);        \
+        }                                                                                             \
+    } while (0)
+    if (variant == 5) {
+        if (mode == 0) {
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, 64, false, 2, 0, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, 0, true>), grid, block, 0, stream, p);
+        } else {
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, 64, false, 2, 0, true>), grid, block, 0, stream, p);
+            else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 2, 0, true>), grid, block, 0, stream, p);
+        }
+    } else if (variant >= 11 && variant <= 14) {   // ablations (wrong results): 11 no LDS stores, 12 no global loads, 13 neither, 14 + no barriers
+#define UV_ABL(A_) do { if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, A_>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 2, A_>), grid, block, 0, stream, p); } while (0)
+        if (variant == 11) UV_ABL(1); else if (variant == 12) UV_ABL(2); else if (variant == 13) UV_ABL(3); else UV_ABL(4);
+    } else if (variant == 3) {
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 4>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 4>), grid, block, 0, stream, p);
+    } else if (variant == 4) {
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 3>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 3>), grid, block, 0, stream, p);
+    } else if (variant == 1) UV_GEMM_LAUNCH(64, true);
+    else if (variant == 2) UV_GEMM_LAUNCH(32, true);
+    else UV_GEMM_LAUNCH(64, false);
     uv_prof_end(stream);
     UV_LAUNCH_CHECK();
     return UV_OK;
