@@ -69,13 +69,19 @@ int univst_unet_reserve(univst_unet* h, int B, int F, int H, int W);
 int univst_unet_forward(univst_unet* h, const void* sample, float timestep, const void* text, int B, int F, int H,
                         int W, int text_len, const univst_pnp* pnp, void* eps_out, void* feat_out, int ft_index,
                         void* stream);
-/* frame-sharded multi-GPU: this rank holds frames [f0, f0+F) of a clip of Ftot frames per branch.
- * comm callbacks are invoked on the host between launches (RCCL via torch.distributed on the Python side). */
-typedef int (*univst_allreduce_fn)(void* user, void* dev_f32, int count, void* stream);
-typedef int (*univst_kv_exchange_fn)(void* user, void* dev_kv_send_last, void* dev_kv_first_bcast, void* dev_kv_recv_prev,
-                                     void* dev_kv_recv_first, int64_t bytes_per_frame, void* stream);
-int univst_unet_set_comm(univst_unet* h, int rank, int world, univst_allreduce_fn ar, univst_kv_exchange_fn kv,
-                         void* user);
+/* frame-sharded multi-GPU: this rank holds frames [rank*F, (rank+1)*F) of a clip of world*F frames
+ * for ALL branches.  comm_ws is a caller-owned device workspace (>= 64 KiB + 4 x the largest K/V frame pack =
+ * B*N*2C fp16); the callbacks are invoked on the host while forward() enqueues work and must enqueue the
+ * collective on the SAME stream forward() was given (RCCL through torch.distributed on the Python side):
+ *   allreduce(user, byte_off, n)         : in-place SUM over ranks of n fp32 at comm_ws + byte_off  (5-D GroupNorm)
+ *   kv_exchange(user, off_send_last, off_first, off_recv_prev, off_recv_first, nbytes):
+ *        rank 0 broadcasts [off_first, +nbytes) (others receive it at off_recv_first); every rank r < world-1
+ *        sends [off_send_last, +nbytes) to r+1, every rank r > 0 receives it at off_recv_prev  (sparse-causal K/V) */
+typedef int (*univst_allreduce_fn)(void* user, int64_t byte_off, int count_f32);
+typedef int (*univst_kv_exchange_fn)(void* user, int64_t off_send_last, int64_t off_first, int64_t off_recv_prev,
+                                     int64_t off_recv_first, int64_t nbytes);
+int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int64_t comm_ws_bytes,
+                         univst_allreduce_fn ar, univst_kv_exchange_fn kv, void* user);
 
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
 /* Y[M,N] = X[M,K] W[N,K]^T + bias + residual; geglu: W rows must be pre-interleaved, writes N/2 columns.
@@ -105,6 +111,11 @@ int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, flo
                                  void* stats_ws, void* stream);
 /* latent_adain on [1,C,F,H,W] (pnp_utils.py:128-139) */
 int univst_latent_adain(const void* cnt, const void* sty, void* out, int C, int F, int HW, void* stream);
+/* the same in two halves for frame shards: stats[c] = {sum, sumsq} of the content over the LOCAL (F,H,W) (the caller
+ * all-reduces them), then apply with the global element count n_total = F_total*H*W */
+int univst_latent_adain_stats(const void* cnt, float* stats2c, int C, int F, int HW, void* stream);
+int univst_latent_adain_apply(const void* cnt, const void* sty, const float* stats2c, int64_t n_total, void* out, int C,
+                              int F, int HW, void* stream);
 /* out = cx*x + ce*eps: DDIMScheduler.step / next_step with host-folded coefficients (stable_diffusion.py:761,
  * ddim_inversion.py:190-204) */
 int univst_axpby(const void* x, const void* eps, void* out, float cx, float ce, int64_t n, void* stream);

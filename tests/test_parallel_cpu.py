@@ -1,0 +1,115 @@
+"""CPU, world_size 2, gloo: the frame-sharding exchange schedule of univst_amd.parallel (the same TorchDistComm
+object the RCCL path uses) reproduces the UNSHARDED oracle: 5-D GroupNorm through all-reduced partial sums,
+sparse-causal attention through a 1-hop halo + rank-0 broadcast, latent_adain through all-reduced content sums."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from oracle import unet_ref
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from univst_amd.parallel import FrameShard, TorchDistComm
+        comm = TorchDistComm()
+        B, Fr, C, H, G, heads = 3, 4, 32, 4, 8, 2
+        N = H * H
+        sh = FrameShard(rank, world, Fr, comm=comm)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(B, C, Fr, H, H, generator=g) * 2 + 0.3
+        gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        # ---- coupling 1: 5-D GroupNorm statistics
+        xl = sh.slice_frames(x)
+        cpg = C // G
+        part = torch.stack([xl.view(B, G, -1).sum(-1), (xl.view(B, G, -1) ** 2).sum(-1)], -1).reshape(-1).contiguous()
+        comm.all_reduce_sum(part)
+        part = part.view(B, G, 2)
+        cnt = Fr * H * H * cpg
+        mean = part[..., 0] / cnt
+        var = part[..., 1] / cnt - mean ** 2
+        yl = (xl.view(B, G, -1) - mean[..., None]) / torch.sqrt(var[..., None] + 1e-5)
+        yl = yl.view_as(xl) * gam[None, :, None, None, None] + bet[None, :, None, None, None]
+        ref = sh.slice_frames(F.group_norm(x, G, gam, bet, 1e-5))
+        assert (yl - ref).abs().max() < 1e-4
+        # ---- coupling 2: sparse-causal attention with halo + broadcast
+        q = torch.randn(B * Fr, N, C, generator=g)
+        k = torch.randn(B * Fr, N, C, generator=g)
+        v = torch.randn(B * Fr, N, C, generator=g)
+        for index in ([-1, 0, "first"], [-1, "first"]):
+            full = unet_ref.sdpa(q, unet_ref.sparse_causal_gather(k, Fr, index), unet_ref.sparse_causal_gather(v, Fr, index), heads)
+            loc = lambda t: t.view(B, Fr, N, C)[:, sh.f0:sh.f0 + sh.local]
+            kl, vl, ql = loc(k), loc(v), loc(q)
+            pack = lambda t, f: torch.cat([kl[:, f], vl[:, f]], -1).contiguous() if t is None else t
+            send_last, first = pack(None, sh.local - 1), pack(None, 0)
+            recv_prev, recv_first = torch.zeros_like(send_last), torch.zeros_like(first)
+            comm.halo_and_broadcast(send_last, first, recv_prev, recv_first)
+            if rank == 0:
+                recv_first, recv_prev = first, first            # frame 0: prev clips to itself
+            outs = []
+            for f in range(sh.local):
+                kp = recv_prev[..., :C] if f == 0 else kl[:, f - 1]
+                vp = recv_prev[..., C:] if f == 0 else vl[:, f - 1]
+                ks, vs = [kp], [vp]
+                if 0 in index:
+                    ks.append(kl[:, f]); vs.append(vl[:, f])
+                ks.append(recv_first[..., :C]); vs.append(recv_first[..., C:])
+                outs.append(unet_ref.sdpa(ql[:, f], torch.cat(ks, 1), torch.cat(vs, 1), heads))
+            got = torch.stack(outs, 1)
+            assert (got - loc(full)).abs().max() < 1e-5, index
+        # ---- coupling 3: latent_adain content statistics; gather
+        c5, s5 = torch.randn(1, 4, Fr, H, H, generator=g), torch.randn(1, 4, Fr, H, H, generator=g) * 0.5 + 0.2
+        cl, sl = sh.slice_frames(c5), sh.slice_frames(s5)
+        st = torch.stack([cl.sum(dim=(0, 2, 3, 4)), (cl ** 2).sum(dim=(0, 2, 3, 4))], -1).reshape(-1).contiguous()
+        comm.all_reduce_sum(st)
+        st = st.view(4, 2)
+        n = Fr * H * H
+        mu = st[:, 0] / n
+        rstd = 1 / torch.sqrt(st[:, 1] / n - mu ** 2 + 1e-5)
+        smu, sstd = sl.mean(dim=(0, 3, 4), keepdim=True), sl.std(dim=(0, 3, 4), keepdim=True)
+        got = (cl - mu[None, :, None, None, None]) * rstd[None, :, None, None, None] * sstd + smu
+        assert (got - sh.slice_frames(unet_ref.latent_adain(c5, s5))).abs().max() < 1e-4
+        assert torch.equal(sh.gather_frames(sh.slice_frames(c5)), c5)
+        out.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_frame_shard_schedule_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
+def test_frame_shard_slicing():
+    from univst_amd.parallel import FrameShard
+    t = torch.arange(2 * 4 * 8).view(1, 2, 8, 2, 2)
+    parts = [FrameShard(r, 4, 8).slice_frames(t) for r in range(4)]
+    assert torch.equal(torch.cat(parts, 2), t)
+    with pytest.raises(ValueError):
+        FrameShard(0, 3, 16)

@@ -25,8 +25,8 @@ class PnP(C.Structure):
                 ("alpha", C.c_float), ("gamma", C.c_float)]
 
 
-ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
-KVEXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int)
+KVEXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
 
 # name -> (restype, argtypes); kept in sync with include/univst.h (tests/test_abi.py checks both ways)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -39,7 +39,7 @@ SIGNATURES = {
     "univst_unet_finalize": (_I, [_P, _P]),
     "univst_unet_reserve": (_I, [_P, _I, _I, _I, _I]),
     "univst_unet_forward": (_I, [_P, _P, _F, _P, _I, _I, _I, _I, _I, C.POINTER(PnP), _P, _P, _I, _P]),
-    "univst_unet_set_comm": (_I, [_P, _I, _I, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
+    "univst_unet_set_comm": (_I, [_P, _I, _I, _P, _L, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_groupnorm_workspace_bytes": (_L, [_L, _I, _I]),
@@ -48,6 +48,8 @@ SIGNATURES = {
     "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _P]),
     "univst_attention_adain_shift": (_I, [_P, _L, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_latent_adain": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "univst_latent_adain_stats": (_I, [_P, _P, _I, _I, _I, _P]),
+    "univst_latent_adain_apply": (_I, [_P, _P, _P, _L, _P, _I, _I, _I, _P]),
     "univst_axpby": (_I, [_P, _P, _P, _F, _F, _L, _P]),
     "univst_mask_blend": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "univst_mask_resize": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -66,8 +66,12 @@ int univst_unet_forward(univst_unet* h, const void* sample, float t, const void*
     UV_REQUIRE(h && sample && text && eps, "unet_forward: null argument");
     return h->impl.forward(H(sample), t, H(text), B, F, Hh, W, text_len, pnp, HM(eps), HM(feat), ft_index, S(s));
 }
-int univst_unet_set_comm(univst_unet* h, int rank, int world, univst_allreduce_fn ar, univst_kv_exchange_fn kv, void* user) {
+int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int64_t comm_ws_bytes, univst_allreduce_fn ar,
+                         univst_kv_exchange_fn kv, void* user) {
     UV_REQUIRE(h && world >= 1 && rank >= 0 && rank < world, "set_comm: bad rank/world");
+    UV_REQUIRE(world == 1 || (comm_ws && comm_ws_bytes >= (1 << 17) && ar && kv), "set_comm: world > 1 needs a workspace and both callbacks");
+    h->impl.comm_ws = (char*)comm_ws;
+    h->impl.comm_ws_bytes = comm_ws_bytes;
     h->impl.rank = rank;
     h->impl.world = world;
     h->impl.allreduce = ar;
@@ -131,6 +135,15 @@ int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, flo
 int univst_latent_adain(const void* cnt, const void* sty, void* out, int C, int F, int HW, void* s) {
     UV_REQUIRE(cnt && sty && out, "latent_adain: null argument");
     return uv_launch_latent_adain(H(cnt), H(sty), HM(out), C, F, HW, S(s));
+}
+int univst_latent_adain_stats(const void* cnt, float* stats, int C, int F, int HW, void* s) {
+    UV_REQUIRE(cnt && stats, "latent_adain_stats: null argument");
+    return uv_launch_latent_adain_stats(H(cnt), stats, C, F, HW, S(s));
+}
+int univst_latent_adain_apply(const void* cnt, const void* sty, const float* stats, int64_t n_total, void* out, int C, int F, int HW,
+                              void* s) {
+    UV_REQUIRE(cnt && sty && stats && out && n_total > 0, "latent_adain_apply: bad argument");
+    return uv_launch_latent_adain_apply(H(cnt), H(sty), stats, n_total, HM(out), C, F, HW, S(s));
 }
 int univst_axpby(const void* x, const void* e, void* out, float cx, float ce, int64_t n, void* s) {
     UV_REQUIRE(x && e && out, "axpby: null argument");

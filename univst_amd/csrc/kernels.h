@@ -36,9 +36,17 @@ struct AttnParams {
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);
+struct UvGnComm {      // cross-rank reduction hook of the 5-D GroupNorm (frame sharding)
+    int world = 1;
+    float* red = nullptr;                                            // device [S*G*2] inside the comm workspace
+    long byte_off = 0;                                               // its byte offset in that workspace
+    int (*allreduce)(void* user, int64_t byte_off, int count_f32) = nullptr;
+    void* user = nullptr;
+};
 int uv_groupnorm_workspace_floats(int S, int G);
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G, float eps,
-                        const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part, hipStream_t stream);
+                        const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part, hipStream_t stream,
+                        const UvGnComm* comm = nullptr);
 int uv_launch_layernorm(const half_t* x, long ldx, half_t* y, long ldy, const half_t* gamma, const half_t* beta, long rows,
                         int C, float eps, hipStream_t stream);
 int uv_launch_attention(const AttnParams& p, hipStream_t stream);
@@ -47,6 +55,11 @@ int uv_launch_colstats(const half_t* x, long ld, int F, int N, int ncols, float*
 int uv_launch_adain_shift(half_t* qkv, long ld, int F, int N, int C, float* mean, float* stdv, float alpha, float beta,
                           float gamma, hipStream_t stream);
 int uv_launch_latent_adain(const half_t* cnt, const half_t* sty, half_t* out, int Cl, int F, int HW, hipStream_t stream);
+int uv_launch_latent_adain_stats(const half_t* cnt, float* st, int Cl, int F, int HW, hipStream_t stream);
+int uv_launch_latent_adain_apply(const half_t* cnt, const half_t* sty, const float* st, long n_total, half_t* out, int Cl, int F, int HW,
+                                 hipStream_t stream);
+int uv_launch_kv_pack(const half_t* qkv, long ld, int C, int N, int B, int frames_per_branch, int frame, half_t* dst, hipStream_t s);
+int uv_launch_kv_unpack(const half_t* src, half_t* qkv, long ld, int C, int N, int B, long row0, hipStream_t s);
 int uv_launch_ncfhw_to_nhwc(const half_t* x, half_t* y, int B, int Cl, int F, int HW, int CP, hipStream_t s);
 int uv_launch_nhwc_to_ncfhw(const half_t* x, int ldx, half_t* y, int B, int Cl, int F, int HW, hipStream_t s);
 int uv_launch_timestep_embed(float t, half_t* out, int B, int dim, int flip, float shift, hipStream_t s);

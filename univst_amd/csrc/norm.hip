@@ -64,7 +64,7 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
 }
 
 __global__ void gn_apply_kernel(const half_t* __restrict__ s1, const half_t* __restrict__ s2, int C1, int C2,
-                                int rows_per_stat, int rows_per_block, int G, int nchunk, float eps,
+                                int rows_per_stat, int rows_per_block, int G, int nchunk, float eps, long count_rows,
                                 const float* __restrict__ part, const half_t* __restrict__ gamma,
                                 const half_t* __restrict__ beta, int silu, half_t* __restrict__ out) {
     extern __shared__ float sm[];                    // [G] mean, [G] rstd
@@ -78,7 +78,7 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ s1, const half_t* __r
             a += pp[0];
             b += pp[1];
         }
-        double cnt = (double)rows_per_stat * cpg;
+        double cnt = (double)count_rows * cpg;
         double mean = a / cnt;
         double var = b / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -118,6 +118,16 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ s1, const half_t* __r
         }
         *reinterpret_cast<h8*>(out + (rbase + r) * C + c0) = o;
     }
+}
+
+// [S, nchunk, G, 2] -> [S, G, 2]: the 768-byte per-(branch, group) partial sums a frame shard all-reduces
+__global__ void gn_reduce_chunks_kernel(const float* __restrict__ part, float* __restrict__ red, int nchunk, int SG2, int G2) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= SG2) return;
+    int s = i / G2, r = i - s * G2;
+    float a = 0.f;
+    for (int c = 0; c < nchunk; ++c) a += part[((long)s * nchunk + c) * G2 + r];
+    red[i] = a;
 }
 
 // LayerNorm over the last dim, one wave per row, row kept in registers (two-pass variance).
@@ -182,7 +192,7 @@ int uv_groupnorm_workspace_floats(int S, int G) { return S * 128 * G * 2; }
 
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G,
                         float eps, const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part,
-                        hipStream_t stream) {
+                        hipStream_t stream, const UvGnComm* comm) {
     const int C = C1 + C2;
     UV_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channels must be multiples of 8 (C1=%d C2=%d)", C1, C2);
     UV_REQUIRE(C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
@@ -208,8 +218,24 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     if (nblk < 1) nblk = 1;
     const int rpb = (rows_per_stat + nblk - 1) / nblk;
     nblk = (rows_per_stat + rpb - 1) / rpb;
+    long count_rows = rows_per_stat;
+    const float* stats = part;
+    int nch_apply = nchunk;
+    if (comm && comm->world > 1) {     // frame shard: sum the partials over ranks (SURVEY §8e coupling 1)
+        const int SG2 = S * G * 2;
+        hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 255) / 256), dim3(256), 0, stream, part, comm->red, nchunk, SG2, G * 2);
+        UV_LAUNCH_CHECK();
+        int rc = comm->allreduce(comm->user, comm->byte_off, SG2);
+        if (rc) {
+            uv_set_error("groupnorm: all-reduce callback failed (%d)", rc);
+            return UV_ERR_STATE;
+        }
+        stats = comm->red;
+        nch_apply = 1;
+        count_rows = (long)rows_per_stat * comm->world;
+    }
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, S), dim3(block), 2 * G * sizeof(float), stream, s1, s2, C1, C2,
-                       rows_per_stat, rpb, G, nchunk, eps, part, gamma, beta, silu, out);
+                       rows_per_stat, rpb, G, nch_apply, eps, count_rows, stats, gamma, beta, silu, out);
     uv_prof_end(stream);
     UV_LAUNCH_CHECK();
     return UV_OK;

@@ -193,7 +193,93 @@ __global__ __launch_bounds__(1024) void latent_adain_kernel(const half_t* __rest
     }
 }
 
+// frame-shard halves of latent_adain: (1) per-channel {sum, sumsq} of the local content frames, (2) apply with
+// the globally reduced statistics.  One block per channel.
+__global__ __launch_bounds__(1024) void latent_adain_stats_kernel(const half_t* __restrict__ cnt, float* __restrict__ st, int n) {
+    __shared__ float red[2][16];
+    const int c = blockIdx.x;
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        float v = (float)cnt[(long)c * n + i];
+        a += v;
+        b += v * v;
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = a;
+        red[1][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double x = 0, y = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+            x += red[0][i];
+            y += red[1][i];
+        }
+        st[c * 2] = (float)x;
+        st[c * 2 + 1] = (float)y;
+    }
+}
+__global__ __launch_bounds__(1024) void latent_adain_apply_kernel(const half_t* __restrict__ cnt, const half_t* __restrict__ sty,
+                                                                  const float* __restrict__ st, double n_total,
+                                                                  half_t* __restrict__ out, int F, int HW) {
+    __shared__ float red[2][16];
+    __shared__ float bc[2];
+    const int c = blockIdx.x;
+    const long base = (long)c * F * HW;
+    const double mu = st[c * 2] / n_total;
+    double var = st[c * 2 + 1] / n_total - mu * mu;
+    if (var < 0) var = 0;
+    const float cmu = (float)mu, crstd = (float)(1.0 / sqrt(var + 1e-5));
+    for (int f = 0; f < F; ++f) {
+        const half_t* sp = sty + base + (long)f * HW;
+        float a = 0.f, b = 0.f;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            float v = (float)sp[i];
+            a += v;
+            b += v * v;
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = a;
+            red[1][threadIdx.x >> 6] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double x = 0, y = 0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) {
+                x += red[0][i];
+                y += red[1][i];
+            }
+            double m = x / HW, v = (y - x * m) / (HW > 1 ? HW - 1 : 1);
+            bc[0] = (float)m;
+            bc[1] = (float)sqrt(v > 0 ? v : 0);
+        }
+        __syncthreads();
+        const float smu = bc[0], sstd = bc[1];
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            long o = base + (long)f * HW + i;
+            out[o] = (half_t)(((float)cnt[o] - cmu) * crstd * sstd + smu);
+        }
+    }
+}
+
 }  // namespace
+
+int uv_launch_latent_adain_stats(const half_t* cnt, float* st, int Cl, int F, int HW, hipStream_t stream) {
+    hipLaunchKernelGGL(latent_adain_stats_kernel, dim3(Cl), dim3(1024), 0, stream, cnt, st, F * HW);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+int uv_launch_latent_adain_apply(const half_t* cnt, const half_t* sty, const float* st, long n_total, half_t* out, int Cl, int F, int HW,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(latent_adain_apply_kernel, dim3(Cl), dim3(1024), 0, stream, cnt, sty, st, (double)n_total, out, F, HW);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
 
 int uv_launch_colstats(const half_t* x, long ld, int F, int N, int ncols, float* mean, float* stdv, hipStream_t stream) {
     UV_REQUIRE(ncols % 8 == 0 && ld % 8 == 0, "colstats: ncols/ld must be multiples of 8");

@@ -46,6 +46,8 @@ struct UNet {
     univst_allreduce_fn allreduce = nullptr;
     univst_kv_exchange_fn kv_exchange = nullptr;
     void* comm_user = nullptr;
+    char* comm_ws = nullptr;
+    long comm_ws_bytes = 0;
 
     ~UNet();
     int load_tensor(const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, hipStream_t s);

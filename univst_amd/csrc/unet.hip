@@ -261,19 +261,24 @@ int UNet::reserve(int B, int F, int H, int Wd) {
     }
     arena.reset();
     // K/V source tables for this (B,F)
-    long key = ((long)B << 20) | F;
+    long key = ((long)B << 20) | F | ((long)rank << 40) | ((long)world << 50);
     if (!idx_tables.count(key)) {
         std::vector<int> t;
+        // frame shard: ranks > 0 find the previous frame of their first local frame and the clip's frame 0 in the
+        // extra K/V frames appended after the B*F local ones ([B prev | B first], filled by Fwd::kv_exchange)
+        const bool ext = world > 1 && rank > 0;
+        auto prev = [&](int b, int f) { return f > 0 ? b * F + f - 1 : (ext ? B * F + b : b * F); };
+        auto first = [&](int b) { return ext ? B * F + B + b : b * F; };
         for (int b = 0; b < B; ++b)
             for (int f = 0; f < F; ++f) {   // stock: [-1, 0, 'first'] (attention.py:356)
-                t.push_back(b * F + (f > 0 ? f - 1 : 0));
+                t.push_back(prev(b, f));
                 t.push_back(b * F + f);
-                t.push_back(b * F);
+                t.push_back(first(b));
             }
         for (int b = 0; b < B; ++b)
             for (int f = 0; f < F; ++f) {   // PnP: [-1, 'first'] (pnp_utils.py:25)
-                t.push_back(b * F + (f > 0 ? f - 1 : 0));
-                t.push_back(b * F);
+                t.push_back(prev(b, f));
+                t.push_back(first(b));
             }
         for (int b = 0; b < B; ++b)
             for (int f = 0; f < F; ++f) t.push_back(b);   // text: one [77, C] block per branch
@@ -311,9 +316,19 @@ struct Fwd {
     void free(void* p) { u.arena.release(p); }
     half_t* W(const std::string& k) { return u.W(k); }
 
-    int groupnorm(const Act& a, const Act* b, int rows_per_stat, float eps, const std::string& p, int silu, half_t* out) {
+    int groupnorm(const Act& a, const Act* b, int rows_per_stat, float eps, const std::string& p, int silu, half_t* out,
+                  bool cross_frame = false) {
+        UvGnComm gc;
+        const bool sharded = cross_frame && u.world > 1;
+        if (sharded) {             // 5-D GroupNorm statistics span all frames of a branch => sum the partials over ranks
+            gc.world = u.world;
+            gc.red = (float*)u.comm_ws;
+            gc.byte_off = 0;
+            gc.allreduce = u.allreduce;
+            gc.user = u.comm_user;
+        }
         return uv_launch_groupnorm(a.p, b ? b->p : nullptr, a.C, b ? b->C : 0, a.rows(), rows_per_stat, u.cfg.norm_num_groups,
-                                   eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s);
+                                   eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s, sharded ? &gc : nullptr);
     }
     int conv(const Act& a, const Act* b, const std::string& p, int Cout, int taps, int stride, int up, const half_t* rowbias,
              const half_t* R, Act* out) {
@@ -370,13 +385,35 @@ struct Fwd {
         return uv_launch_gemm(g, 0, s);
     }
 
+    // frame shard (SURVEY §8e coupling 2): every frame attends to {prev, (cur), first}; the previous frame of this
+    // rank's first frame lives on rank-1 and frame 0 on rank 0.  Packs are [B, N, 2C] (K|V of one frame per branch).
+    int kv_exchange(half_t* qkv, int C, int N) {
+        const long nbytes = (long)B * N * 2 * C * sizeof(half_t);
+        const long slot = ((u.comm_ws_bytes - 65536) / 4) & ~255L;
+        UV_REQUIRE(nbytes <= slot, "kv_exchange: comm workspace too small (%ld B per slot, need %ld)", slot, nbytes);
+        const long o_send = 65536, o_first = o_send + slot, o_prev = o_first + slot, o_rfirst = o_prev + slot;
+        if (u.rank < u.world - 1) RUN(uv_launch_kv_pack(qkv, 3 * C, C, N, B, F, F - 1, (half_t*)(u.comm_ws + o_send), s));
+        if (u.rank == 0) RUN(uv_launch_kv_pack(qkv, 3 * C, C, N, B, F, 0, (half_t*)(u.comm_ws + o_first), s));
+        int rc = u.kv_exchange(u.comm_user, o_send, o_first, o_prev, o_rfirst, nbytes);
+        if (rc) {
+            uv_set_error("kv_exchange callback failed (%d)", rc);
+            return UV_ERR_STATE;
+        }
+        if (u.rank > 0) {
+            const long row0 = (long)B * F * N;
+            RUN(uv_launch_kv_unpack((const half_t*)(u.comm_ws + o_prev), qkv, 3 * C, C, N, B, row0, s));
+            RUN(uv_launch_kv_unpack((const half_t*)(u.comm_ws + o_rfirst), qkv, 3 * C, C, N, B, row0 + (long)B * N, s));
+        }
+        return UV_OK;
+    }
+
     // resnet.py:335-394
     int resblock(const std::string& p, const Act& x, const Act* skip, int Cout, Act* out) {
         const int Cin = x.C + (skip ? skip->C : 0);
         const int rps = F * x.H * x.W;
         half_t* n1 = alloc(x.rows() * Cin);
         if (!n1) return UV_ERR_STATE;
-        RUN(groupnorm(x, skip, rps, u.cfg.norm_eps, p + ".norm1", 1, n1));
+        RUN(groupnorm(x, skip, rps, u.cfg.norm_eps, p + ".norm1", 1, n1, true));
         half_t* tp = alloc((long)B * Cout);
         if (!tp) return UV_ERR_STATE;
         half_t *tw = W(p + ".time_emb_proj.weight"), *tb = W(p + ".time_emb_proj.bias");
@@ -387,7 +424,7 @@ struct Fwd {
         free(n1);
         half_t* n2 = alloc(h.rows() * Cout);
         if (!n2) return UV_ERR_STATE;
-        RUN(groupnorm(h, nullptr, rps, u.cfg.norm_eps, p + ".norm2", 1, n2));
+        RUN(groupnorm(h, nullptr, rps, u.cfg.norm_eps, p + ".norm2", 1, n2, true));
         free(h.p);
         free(tp);
         const half_t* res = x.p;
@@ -421,7 +458,8 @@ struct Fwd {
         gm = W(b + ".norm1.weight"); bt = W(b + ".norm1.bias");
         if (!gm || !bt) return u.missing_error();
         RUN(uv_launch_layernorm(h, C, t0, C, gm, bt, rows, C, 1e-5f, s));
-        half_t* qkv = alloc(rows * 3 * C);
+        const long extra_rows = u.world > 1 ? (long)2 * B * N : 0;     // received prev-frame + first-frame K/V (frame shard)
+        half_t* qkv = alloc((rows + extra_rows) * 3 * C);
         if (!qkv) return UV_ERR_STATE;
         RUN(linear(t0, C, rows, C, b + ".attn1.qkv#fused", "", 3 * C, qkv, 3 * C));
         const bool registered = pnp_layer && pnp && pnp->registered;
@@ -430,6 +468,7 @@ struct Fwd {
             const float beta = (0.9f - 0.1f) / (pnp->eta1 * 50.f - pnp->eta2 * 50.f) * ((float)pnp->idx - pnp->eta2 * 50.f) + 0.1f;
             RUN(uv_launch_adain_shift(qkv, 3 * C, F, N, C, ad_ws, ad_ws + (long)F * 2 * C, pnp->alpha, beta, pnp->gamma, s));
         }
+        if (u.world > 1) RUN(kv_exchange(qkv, C, N));
         AttnParams ap;
         ap.q = qkv; ap.k = qkv + C; ap.v = qkv + 2 * C;
         ap.ldq = ap.ldkv = 3 * C;
@@ -506,7 +545,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     const int C0 = boc[0], TED = 4 * C0, L = cfg.layers_per_block;
     Fwd f{*this, s, B, F, text_len, pnp};
     f.text = text;
-    const int* tab = idx_tables[((long)B << 20) | F];
+    const int* tab = idx_tables[((long)B << 20) | F | ((long)rank << 40) | ((long)world << 50)];
     f.idx_stock = tab;
     f.idx_pnp = tab + (long)B * F * 3;
     f.idx_text = tab + (long)B * F * 5;
@@ -607,7 +646,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     // ---- out
     half_t* n = f.alloc(x.rows() * x.C);
     if (!n) return UV_ERR_STATE;
-    RUN(f.groupnorm(x, nullptr, F * x.H * x.W, cfg.norm_eps, "conv_norm_out", 1, n));
+    RUN(f.groupnorm(x, nullptr, F * x.H * x.W, cfg.norm_eps, "conv_norm_out", 1, n, true));
     Act na{n, x.imgs, x.H, x.W, x.C}, y;
     RUN(f.conv(na, nullptr, "conv_out", cfg.out_channels, 9, 1, 0, nullptr, nullptr, &y));
     RUN(uv_launch_nhwc_to_ncfhw(y.p, cfg.out_channels, eps_out, B, cfg.out_channels, F, H * Wd, s));

@@ -1,25 +1,201 @@
-"""Frame sharding of the three-branch loop over the GPUs of one node (one process per GPU, RCCL over xGMI).
+"""Frame sharding of the three-branch loop over the GPUs of one node: one process per GPU, RCCL over xGMI through
+``torch.distributed`` (backend "nccl" == RCCL on ROCm).
 
-Rank r owns frames [f0, f0+Fl) of ALL THREE branches (so the PnP injection stays local).  See DESIGN.md
-§multi-GPU for the exchange schedule."""
+Rank r owns frames [r*Fl, (r+1)*Fl) of ALL THREE branches, so the PnP injection (content/style -> stylised
+branch) and every per-frame op stay local.  Three couplings cross ranks:
+
+  1. 5-D GroupNorm (45 per UNet call): statistics span all frames of a branch -> the native graph reduces its
+     partial sums to [B, groups, 2] fp32 (768 B) and calls back ``allreduce`` (SUM, in place).
+  2. sparse-causal attn1 (16 per UNet call): frame f attends to {f-1, (f), 0}.  The previous frame of a rank's
+     first local frame lives on rank-1 and frame 0 on rank 0 -> a 1-hop halo send/recv plus a broadcast from
+     rank 0 of one [B, N, 2C] K|V pack each (not an all-gather of all K/V: 8x fewer bytes on the per-link-bound
+     xGMI ring).
+  3. latent_adain (1 + 5 calls per run): content statistics over (F,h,w) -> all-reduce of [C, 2] fp32.
+
+The native library never links RCCL: it calls back into this module on the host while it enqueues the UNet, and the
+callbacks enqueue the collective on the same stream (torch.distributed orders its communicator stream against the
+current stream with events).  ``Comm`` is the only object that touches ``torch.distributed``; tests swap it for
+``ThreadLoopbackComm`` (ranks = host threads sharing one GPU) to validate the exchange schedule on a 1-GPU box, and
+for a gloo-backed CPU instance to validate the sharded algorithm against the unsharded oracle.
+"""
+import ctypes as C
+import threading
+from typing import List, Optional
+
 import torch
+
+from . import _native
 
 
 class FrameShard:
-    def __init__(self, rank: int, world: int, frames: int):
+    def __init__(self, rank: int, world: int, frames: int, comm=None):
         if frames % world != 0:
             raise ValueError(f"frames={frames} must be divisible by the number of GPUs ({world})")
         self.rank, self.world, self.frames = rank, world, frames
         self.local = frames // world
         self.f0 = rank * self.local
+        self.comm = comm
+        self._keep = []          # ctypes callbacks + workspace must outlive the native handle
+        self.ws = None
 
+    # ------------------------------------------------------------------ data layout
     def slice_frames(self, t: torch.Tensor) -> torch.Tensor:
         """[.., .., F, h, w] -> this rank's frames (contiguous)."""
         if self.world == 1:
             return t
         return t[:, :, self.f0:self.f0 + self.local].contiguous()
 
-    def attach(self, unet):
+    def gather_frames(self, t: torch.Tensor) -> torch.Tensor:
+        """inverse of slice_frames on every rank (final latents -> full clip)."""
+        if self.world == 1:
+            return t
+        return torch.cat(self.comm.all_gather(t.contiguous()), dim=2)
+
+    # ------------------------------------------------------------------ native hooks
+    def attach(self, unet, max_tokens: int = 4096, max_channels: int = None, branches: int = 3):
+        """register the comm callbacks + workspace on the UNet's native handle (no-op for world == 1)."""
         if self.world == 1:
             return
-        raise NotImplementedError("multi-GPU frame sharding: see univst_amd/parallel.py")
+        if self.comm is None:
+            self.comm = TorchDistComm()
+        unet._sync_native()
+        boc = unet.config.block_out_channels
+        cmax = max_channels or max(boc)
+        # largest K|V pack: B * N * 2C fp16 over the attention levels (N shrinks 4x per level while C grows <= 2x)
+        pack = max(branches * (max_tokens >> (2 * i)) * 2 * c * 2 for i, c in enumerate(boc[:3]))
+        nbytes = 65536 + 4 * ((pack + 255) // 256 * 256) + 4096
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=unet.device)
+        ws, comm = self.ws, self.comm
+
+        def allreduce(user, byte_off, count):
+            try:
+                comm.all_reduce_sum(ws[byte_off:byte_off + 4 * count].view(torch.float32))
+                return 0
+            except Exception as e:  # pragma: no cover
+                print(f"[univst_amd.parallel] all-reduce failed: {e!r}")
+                return 1
+
+        def kv_exchange(user, off_send, off_first, off_prev, off_rfirst, nb):
+            try:
+                comm.halo_and_broadcast(ws[off_send:off_send + nb], ws[off_first:off_first + nb], ws[off_prev:off_prev + nb],
+                                        ws[off_rfirst:off_rfirst + nb])
+                return 0
+            except Exception as e:  # pragma: no cover
+                print(f"[univst_amd.parallel] K/V exchange failed: {e!r}")
+                return 1
+
+        ar, kv = _native.ALLREDUCE_FN(allreduce), _native.KVEXCHANGE_FN(kv_exchange)
+        self._keep += [ar, kv]
+        _native.check(_native.load().univst_unet_set_comm(unet._native_handle, self.rank, self.world, ws.data_ptr(), nbytes, ar, kv,
+                                                          None), "unet_set_comm")
+        unet._frame_shard = self
+
+    # ------------------------------------------------------------------ sharded latent_adain (pnp_utils.py:128-139)
+    def latent_adain(self, cnt: torch.Tensor, sty: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return _native.latent_adain(cnt, sty)
+        lib = _native.load()
+        _, Cl, Fl, H, W = cnt.shape
+        st = torch.empty(Cl * 2, device=cnt.device, dtype=torch.float32)
+        _native.check(lib.univst_latent_adain_stats(cnt.data_ptr(), st.data_ptr(), Cl, Fl, H * W, _native.stream_ptr()), "adain_stats")
+        self.comm.all_reduce_sum(st)
+        out = torch.empty_like(cnt)
+        _native.check(lib.univst_latent_adain_apply(cnt.data_ptr(), sty.data_ptr(), st.data_ptr(), self.frames * H * W, out.data_ptr(),
+                                                    Cl, Fl, H * W, _native.stream_ptr()), "adain_apply")
+        return out
+
+    # ------------------------------------------------------------------ one step of the transfer loop on the local frames
+    def make_step_fn(self, pipe, content, style, text3, mask_m=None, n=50):
+        from . import engine
+        from .backbones.video_diffusion_sd.pnp_utils import register_time
+        ts = pipe.scheduler.timesteps
+
+        def step(i, latents):
+            i = i % n
+            t = ts[i]
+            c_t, s_t = content[n - i], style[n - i]
+            if mask_m is not None and i <= 0.9 * n:
+                latents = _native.mask_blend(latents, c_t, mask_m)
+            if i > 0.8 * n and i <= 0.9 * n:
+                latents = _native.mask_blend(self.latent_adain(latents, s_t), c_t, mask_m)
+            register_time(pipe, i)
+            x = torch.cat([c_t, s_t, latents])
+            eps = pipe.unet(x, t, encoder_hidden_states=text3).sample[2:3]
+            return engine.ddim_step(pipe.scheduler, eps, t, latents)
+        return step
+
+
+# ------------------------------------------------------------------------------------------------ communicators
+class TorchDistComm:
+    """RCCL (or gloo on CPU) through torch.distributed; all ops are enqueued against the current stream."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t, group=self.group)
+        return outs
+
+    def halo_and_broadcast(self, send_last, first, recv_prev, recv_first):
+        """rank 0 broadcasts `first` (others receive into `recv_first`); r -> r+1 halo of `send_last` into `recv_prev`."""
+        dist, r, w = self.dist, self.rank, self.world
+        dist.broadcast(first if r == 0 else recv_first, src=0, group=self.group)
+        ops = []
+        if r < w - 1:
+            ops.append(dist.P2POp(dist.isend, send_last, r + 1, self.group))
+        if r > 0:
+            ops.append(dist.P2POp(dist.irecv, recv_prev, r - 1, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+
+class ThreadLoopbackComm:
+    """`world` host threads of ONE process play the ranks (each with its own native UNet handle and its own HIP stream
+    on the same GPU).  Collectives are rendezvous on a threading.Barrier plus device copies — the same call sites and
+    the same buffers as the RCCL path, so the exchange schedule is validated on a 1-GPU box."""
+
+    class Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots: List[Optional[dict]] = [None] * world
+
+    def __init__(self, shared: "ThreadLoopbackComm.Shared", rank: int):
+        self.sh, self.rank, self.world = shared, rank, shared.world
+
+    def _publish(self, **tensors):
+        torch.cuda.current_stream().synchronize()        # my data is complete before the others read it
+        self.sh.slots[self.rank] = tensors
+        self.sh.barrier.wait()
+
+    def _done(self):
+        torch.cuda.current_stream().synchronize()        # my reads are complete before the others overwrite
+        self.sh.barrier.wait()
+
+    def all_reduce_sum(self, t):
+        self._publish(t=t)
+        total = sum(self.sh.slots[r]["t"].clone() for r in range(self.world))
+        self._done()
+        t.copy_(total)
+
+    def all_gather(self, t):
+        self._publish(t=t)
+        outs = [self.sh.slots[r]["t"].clone() for r in range(self.world)]
+        self._done()
+        return outs
+
+    def halo_and_broadcast(self, send_last, first, recv_prev, recv_first):
+        self._publish(send_last=send_last, first=first)
+        if self.rank > 0:
+            recv_first.copy_(self.sh.slots[0]["first"])
+            recv_prev.copy_(self.sh.slots[self.rank - 1]["send_last"])
+        self._done()
