@@ -93,6 +93,11 @@ int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, c
 int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, int stride,
                      int taps, const void* W, const void* bias, const void* rowbias, int rows_per_rowbias,
                      const void* residual, void* Y, int Cout, void* stream);
+/* the same 3x3 conv with the "tap-inner" weight layout [Cout][(C1+C2)/64][9][64] (C1, C2 multiples of 64): the nine taps
+ * of a 64-channel slab are consecutive k tiles, which keeps the re-read activation rows in the XCD's L2. */
+int univst_conv_nhwc_tapinner(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, int stride,
+                              const void* W, const void* bias, const void* rowbias, int rows_per_rowbias,
+                              const void* residual, void* Y, int Cout, void* stream);
 /* GroupNorm(+SiLU) on NHWC rows; rows_per_stat = F*H*W (5-D, stats across frames: resnet.py:338,369) or H*W
  * (per frame: attention.py:121).  workspace: univst_groupnorm_workspace_bytes(). */
 int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups);
@@ -145,10 +150,11 @@ int univst_accumulate_u8(const uint8_t* frame, float* acc, int64_t n, void* stre
 int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ per-kernel-class HIP-event timing (bench.py roofline leg)
- * classes: 0 linear GEMM, 1 implicit-GEMM conv, 2 attention, 3 groupnorm, 4 layernorm, 5 adain shift.
+ * classes (one per kernel symbol): 0 gemm_big<0>, 1 gemm_big<1> (conv), 2 gemm_kernel<*,0> (linear), 3 gemm_kernel<*,1>
+ * (conv), 4 attention d=40, 5 attention d=80, 6 other attention, 7 groupnorm, 8 layernorm, 9 adain shift.
  * While enabled every launch of these classes is bracketed by hipEvents on its stream; collect() waits for
  * them and returns per class: summed ms, launch count, algorithmic flops and algorithmic bytes. */
-#define UNIVST_PROFILE_CLASSES 6
+#define UNIVST_PROFILE_CLASSES 10
 int univst_profile_enable(int on);
 int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int nclasses);
 

@@ -128,6 +128,26 @@ def test_conv3x3(nat, Ci, Co, H, stride, up):
     close(got, nhwc(ref))
 
 
+def conv_w_ti(w):   # [Co,Ci,3,3] -> [Co,Ci/64,9,64]
+    Co, Ci = w.shape[:2]
+    return w.reshape(Co, Ci // 64, 64, 9).permute(0, 1, 3, 2).contiguous()
+
+
+@pytest.mark.parametrize("C1,C2,Co,H,imgs,stride,up", [(64, 0, 64, 16, 6, 1, False), (128, 64, 96, 12, 6, 2, False),
+                                                         (64, 64, 320, 56, 48, 1, False), (64, 0, 320, 28, 48, 1, True)])
+def test_conv3x3_tap_inner_order(nat, C1, C2, Co, H, imgs, stride, up):
+    x1 = rnd(imgs, C1, H, H, seed=1)
+    x2 = rnd(imgs, C2, H, H, seed=2) if C2 else None
+    w = rnd(Co, C1 + C2, 3, 3, seed=3, scale=1 / math.sqrt(9 * (C1 + C2)))
+    b = rnd(Co, seed=4)
+    xin = torch.cat([x1, x2], 1).float() if C2 else x1.float()
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1)
+    got = nat.conv_nhwc_tapinner(nhwc(x1), conv_w_ti(w), bias=b, x2=None if x2 is None else nhwc(x2), upsample=up, stride=stride)
+    close(got, nhwc(ref))
+
+
 def test_conv_concat_rowbias_residual(nat):
     imgs, Fr, C1, C2, Co, H = 6, 2, 64, 32, 64, 8      # 3 "branches" x 2 frames
     x1, x2 = rnd(imgs, C1, H, H, seed=1), rnd(imgs, C2, H, H, seed=2)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "univst_unet_set_comm": (_I, [_P, _I, _I, _P, _L, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_groupnorm_workspace_bytes": (_L, [_L, _I, _I]),
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
@@ -135,6 +136,20 @@ def conv_nhwc(x1, w, bias=None, x2=None, upsample=False, stride=1, rowbias=None,
     return out
 
 
+def conv_nhwc_tapinner(x1, w_ti, bias=None, x2=None, upsample=False, stride=1, rowbias=None, rows_per_rowbias=1, residual=None):
+    """3x3 conv with the tap-inner weight layout [Cout, Cin/64, 9, 64]."""
+    _f16(x1), _f16(w_ti)
+    imgs, Hs, Ws, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cout = w_ti.shape[0]
+    He, We = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    Ho, Wo = (He - 1) // stride + 1, (We - 1) // stride + 1
+    out = torch.empty(imgs, Ho, Wo, Cout, device=x1.device, dtype=torch.float16)
+    check(load().univst_conv_nhwc_tapinner(ptr(x1), ptr(x2), C1, C2, imgs, Hs, Ws, int(upsample), stride, ptr(w_ti), ptr(bias),
+                                           ptr(rowbias), rows_per_rowbias, ptr(residual), ptr(out), Cout, stream_ptr()), "conv_tapinner")
+    return out
+
+
 def groupnorm_nhwc(x1, gamma, beta, groups, eps, rows_per_stat, silu=False, x2=None):
     _f16(x1)
     C1 = x1.shape[-1]
@@ -215,7 +230,8 @@ def debug_tr16():
     return out
 
 
-PROFILE_CLASSES = ("gemm", "conv", "attention", "groupnorm", "layernorm", "adain")
+PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>", "gemm_kernel<*,1>", "attn_kernel_occ3<64,3,2>",
+                   "attn_kernel_occ3<96,5,2>", "attn_kernel<other>", "groupnorm", "layernorm", "adain_shift")
 
 
 def profile_enable(on: bool):

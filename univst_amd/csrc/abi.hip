@@ -104,6 +104,21 @@ int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, i
     g.R = H(R); g.ldr = Cout; g.Y = HM(Y); g.ldy = Cout;
     return uv_launch_gemm(g, 1, S(s));
 }
+int univst_conv_nhwc_tapinner(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int up, int stride,
+                              const void* W, const void* bias, const void* rowbias, int rows_per_rb, const void* R, void* Y, int Cout,
+                              void* s) {
+    UV_REQUIRE(X1 && W && Y, "conv: null argument");
+    UV_REQUIRE((X2 != nullptr) == (C2 > 0), "conv: X2/C2 mismatch");
+    GemmParams g;
+    g.X = H(X1); g.X2 = H(X2); g.C1 = C1; g.C2 = C2; g.Hs = Hs; g.Ws = Ws; g.up = up ? 1 : 0; g.stride = stride; g.taps = 9; g.korder = 1;
+    const int He = Hs << g.up, We = Ws << g.up;
+    g.Ho = (He - 1) / stride + 1;
+    g.Wo = (We - 1) / stride + 1;
+    g.M = imgs * g.Ho * g.Wo; g.N = Cout; g.K = 9 * (C1 + C2);
+    g.W = H(W); g.bias = H(bias); g.rowbias = H(rowbias); g.rows_per_rb = rows_per_rb > 0 ? rows_per_rb : 1;
+    g.R = H(R); g.ldr = Cout; g.Y = HM(Y); g.ldy = Cout;
+    return uv_launch_gemm(g, 1, S(s));
+}
 int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups) {
     if (rows_per_stat <= 0) return 0;
     return (int64_t)uv_groupnorm_workspace_floats((int)(rows / rows_per_stat), groups) * 4;

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
     }
     const int Cin = p.C1 + p.C2;
     int tap = 0, cc = kc * 8;          // MODE 1: (tap, channel) of this thread's chunk in the current k tile
-    if (MODE == 1) {
+    if (MODE == 1 && !p.korder) {
         while (cc >= Cin) { cc -= Cin; ++tap; }
     }
 
@@ -197,8 +197,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
     };
     auto advance_k = [&]() {
         if (MODE == 1) {
-            cc += BK;
-            while (cc >= Cin) { cc -= Cin; ++tap; }
+            if (p.korder) {            // tap-inner: next tap of the same 64-channel slab, then the next slab
+                if (++tap == 9) { tap = 0; cc += 64; }
+            } else {
+                cc += BK;
+                while (cc >= Cin) { cc -= Cin; ++tap; }
+            }
         }
     };
     auto store_tile = [&](int buf) {
@@ -365,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
     const int Cin = p.C1 + p.C2;
     int tap = 0, cc = kc * 8;
-    if (MODE == 1) {
+    if (MODE == 1 && !p.korder) {
         while (cc >= Cin) { cc -= Cin; ++tap; }
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -400,8 +404,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 5; ++i) glds16((w_ok[i] && kok) ? p.W + woff[i] + k0 : zp, Wd + 64 * i * LDSH);
         if (MODE == 1) {
-            cc += BK;
-            while (cc >= Cin) { cc -= Cin; ++tap; }
+            if (p.korder) {
+                if (++tap == 9) { tap = 0; cc += 64; }
+            } else {
+                cc += BK;
+                while (cc >= Cin) { cc -= Cin; ++tap; }
+            }
         }
     };
 
@@ -486,14 +494,17 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         UV_REQUIRE(p.C1 % 8 == 0 && p.C2 % 8 == 0, "conv: channel counts must be multiples of 8 (C1=%d C2=%d)", p.C1, p.C2);
         UV_REQUIRE(p.taps == 1 || p.taps == 9, "conv: taps=%d", p.taps);
         UV_REQUIRE(p.K == p.taps * (p.C1 + p.C2), "conv: K=%d != taps*(C1+C2)", p.K);
+        UV_REQUIRE(!p.korder || (p.taps == 9 && p.C1 % 64 == 0 && p.C2 % 64 == 0), "conv: tap-inner k order needs taps=9 and 64-channel slabs");
     }
     static const int variant0 = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
         static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
         const long nblk = (long)((p.M + 255) / 256) * (p.N / 320);
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
-        if (!nobig && p.N % 320 == 0 && nblk >= 512 && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
-            uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
+        static const long bigmin_env = getenv("UNIVST_GEMM_BIGMIN") ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 0;
+        const long bigmin = bigmin_env ? bigmin_env : (mode == 1 ? 150 : 512);   // measured cross-over (tools/bench_gemm.py)
+        if (!nobig && p.N % 320 == 0 && nblk >= bigmin && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
+            uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : UV_CLS_CONV_BIG, 2.0 * p.M * (double)p.N * p.K,
                           2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
             if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)nblk), dim3(512), 0, stream, p);
             else hipLaunchKernelGGL((gemm_big_kernel<1>), dim3((unsigned)nblk), dim3(512), 0, stream, p);

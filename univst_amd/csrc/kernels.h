@@ -12,6 +12,10 @@ struct GemmParams {
     int M = 0, N = 0, K = 0;
     // MODE 1 geometry
     int C1 = 0, C2 = 0, Hs = 1, Ws = 1, up = 0, Ho = 1, Wo = 1, stride = 1, taps = 1;
+    // korder 0: K index = tap*(C1+C2) + c.  korder 1 ("tap-inner", needs C1 % 64 == C2 % 64 == 0, taps == 9):
+    // K index = (c/64)*576 + tap*64 + c%64 — the 9 taps of one 64-channel slab are consecutive k tiles, so the
+    // activation rows a block re-reads for the shifted taps are still in its XCD's L2 (9x less beyond-L2 traffic).
+    int korder = 0;
     // epilogue
     const half_t* bias = nullptr;      // [N]
     const half_t* rowbias = nullptr;   // [M / rows_per_rb, N]  (time-embedding add per branch)
@@ -77,7 +81,21 @@ int uv_launch_accumulate_u8(const uint8_t* f, float* acc, long n, hipStream_t s)
 int uv_launch_window_store(const float* acc, float weight, uint8_t* dst, long n, hipStream_t s);
 
 // ---- optional per-class HIP-event profiling (prof.hip)
-enum { UV_CLS_GEMM = 0, UV_CLS_CONV = 1, UV_CLS_ATTN = 2, UV_CLS_GROUPNORM = 3, UV_CLS_LAYERNORM = 4, UV_CLS_ADAIN = 5, UV_NCLS = 6 };
+// one class per kernel SYMBOL that matters, so bench.py's average launch duration is comparable with the
+// rocprofv3 --stats row of the same name
+enum {
+    UV_CLS_GEMM_BIG = 0,    // gemm_big_kernel<0>
+    UV_CLS_CONV_BIG = 1,    // gemm_big_kernel<1>
+    UV_CLS_GEMM = 2,        // gemm_kernel<*,0,...>
+    UV_CLS_CONV = 3,        // gemm_kernel<*,1,...>
+    UV_CLS_ATTN_D40 = 4,    // attn_kernel*<64,3,*>
+    UV_CLS_ATTN_D80 = 5,    // attn_kernel*<96,5,*>
+    UV_CLS_ATTN_OTHER = 6,  // remaining attention instantiations
+    UV_CLS_GROUPNORM = 7,
+    UV_CLS_LAYERNORM = 8,
+    UV_CLS_ADAIN = 9,
+    UV_NCLS = 10
+};
 void uv_prof_enable(int on);
 bool uv_prof_on();
 void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s);

@@ -38,6 +38,17 @@ __global__ void permute_conv_weight_kernel(const half_t* __restrict__ in, half_t
     int o = (int)(i / ((long)CiP * taps));
     out[i] = c < Ci ? in[((long)o * Ci + c) * taps + t] : (half_t)0.f;
 }
+// [Co,Ci,3,3] -> tap-inner [Co][Ci/64][9][64]
+__global__ void permute_conv_weight_ti_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int Co, int Ci) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)Co * Ci * 9;
+    if (i >= total) return;
+    int j = (int)(i % 64);
+    int t = (int)((i / 64) % 9);
+    int q = (int)((i / (64 * 9)) % (Ci / 64));
+    int o = (int)(i / ((long)Ci * 9));
+    out[i] = in[((long)o * Ci + q * 64 + j) * 9 + t];
+}
 // GEGLU row interleave: out row (32q + j) = in row (16q + j), out row (32q+16+j) = in row (half + 16q + j)
 __global__ void geglu_interleave_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int rows, int cols) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,6 +217,12 @@ int UNet::finalize(hipStream_t s) {
             if (rc) return rc;
             long n = (long)Co * taps * CiP;
             hipLaunchKernelGGL(permute_conv_weight_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, d, Co, Ci, taps, CiP);
+            if (taps == 9 && Ci % 64 == 0) {      // tap-inner copy (GemmParams::korder = 1)
+                half_t* d2;
+                rc = derive_alloc(k + "#ti", {Co, Ci / 64, 9, 64}, &d2);
+                if (rc) return rc;
+                hipLaunchKernelGGL(permute_conv_weight_ti_kernel, dim3(nb((long)Co * Ci * 9)), dim3(256), 0, s, t.ptr, d2, Co, Ci);
+            }
         } else if (ends(k, ".attn1.to_q.weight")) {
             std::string p = k.substr(0, k.size() - strlen("to_q.weight"));
             const WTensor *tk = find(p + "to_k.weight"), *tv = find(p + "to_v.weight");
@@ -348,7 +365,8 @@ struct Fwd {
         g.M = a.imgs * g.Ho * g.Wo;
         g.N = Cout;
         g.K = taps * (g.C1 + g.C2);
-        g.W = W(p + ".weight#nhwc");
+        g.korder = (taps == 9 && g.C1 % 64 == 0 && g.C2 % 64 == 0 && u.find(p + ".weight#ti")) ? 1 : 0;
+        g.W = W(p + (g.korder ? ".weight#ti" : ".weight#nhwc"));
         g.bias = W(p + ".bias");
         g.rowbias = rowbias;
         g.rows_per_rb = F * g.Ho * g.Wo;
