@@ -22,6 +22,15 @@ constexpr float DEFER = 8.f;   // deferred-rescale threshold in the exp2 domain 
 
 typedef __fp16 fh2 __attribute__((ext_vector_type(2)));
 
+// 3-input max in ONE VALU op.  Written as inline asm because hipcc canonicalises (v_max_f32 x,x) every MFMA result
+// before fmaxf() — 44 extra VALU instructions per key tile in this kernel (guide T17 / MI355X_MICROARCH "price of fillers").
+// Inputs are never NaN here (finite scores or -inf masks), so IEEE NaN quieting is not needed.
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 template <int DPAD, int DV16, int QB>
 __device__ __forceinline__ void attn_body(const AttnParams& p) {
     constexpr int KSTR = lds_stride_bytes(DPAD * 2) / 2;
@@ -74,24 +83,52 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     const int ntile = (p.Nkv + KT - 1) / KT;
     const int T = p.nsrc * ntile;
     h8 kr[NKL], vr[NVL];
+    // per-thread staging geometry is tile-invariant: element offsets inside a [64-key] tile and validity of the chunk
+    unsigned koff[NKL], voff[NVL];
+    int krow[NKL], vrow[NVL];
+    bool kval[NKL], vval[NVL], vone[NVL];
+#pragma unroll
+    for (int i = 0; i < NKL; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / KCH, ch = idx - row * KCH;
+        krow[i] = row;
+        kval[i] = (idx < KT * KCH) && (ch * 8 < d);
+        koff[i] = (unsigned)(row * (int)p.ldkv + h * d + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / VCH, ch = idx - row * VCH;
+        vrow[i] = row;
+        vval[i] = (idx < KT * VCH) && (ch * 8 < d);
+        vone[i] = ONES && (idx < KT * VCH) && (ch * 8 == d);
+        voff[i] = (unsigned)(row * (int)p.ldkv + h * d + ch * 8);
+    }
     auto load_tile = [&](int tt) {        // global -> registers (flies under the MFMAs of the previous tile)
         const int s = tt / ntile, t0 = (tt - s * ntile) * KT;
         const long src = p.src_idx[bf * p.nsrc + s];
+        const half_t* kb = p.k + (src * p.Nkv + t0) * p.ldkv;
+        const half_t* vb = p.v + (src * p.Nkv + t0) * p.ldkv;
+        if (t0 + KT <= p.Nkv) {            // full tile (block-uniform): no per-row checks
 #pragma unroll
-        for (int i = 0; i < NKL; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / KCH, ch = idx - row * KCH;
-            const bool ok = (idx < KT * KCH) && (t0 + row < p.Nkv) && (ch * 8 < d);
-            kr[i] = ok ? *reinterpret_cast<const h8*>(p.k + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
-        }
+            for (int i = 0; i < NKL; ++i) kr[i] = kval[i] ? *reinterpret_cast<const h8*>(kb + koff[i]) : zero8;
 #pragma unroll
-        for (int i = 0; i < NVL; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / VCH, ch = idx - row * VCH;
-            const bool rok = (idx < KT * VCH) && (t0 + row < p.Nkv);
-            h8 v = (rok && ch * 8 < d) ? *reinterpret_cast<const h8*>(p.v + (src * p.Nkv + t0 + row) * p.ldkv + h * d + ch * 8) : zero8;
-            if (ONES && rok && ch * 8 == d) v[0] = (half_t)1.f;
-            vr[i] = v;
+            for (int i = 0; i < NVL; ++i) {
+                h8 v = vval[i] ? *reinterpret_cast<const h8*>(vb + voff[i]) : zero8;
+                if (vone[i]) v[0] = (half_t)1.f;
+                vr[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NKL; ++i)
+                kr[i] = (kval[i] && t0 + krow[i] < p.Nkv) ? *reinterpret_cast<const h8*>(kb + koff[i]) : zero8;
+#pragma unroll
+            for (int i = 0; i < NVL; ++i) {
+                const bool rok = t0 + vrow[i] < p.Nkv;
+                h8 v = (vval[i] && rok) ? *reinterpret_cast<const h8*>(vb + voff[i]) : zero8;
+                if (vone[i] && rok) v[0] = (half_t)1.f;
+                vr[i] = v;
+            }
         }
     };
     auto store_tile = [&](half_t* Ks, half_t* Vs) {
@@ -149,12 +186,20 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             // row max over raw scores (lane-local over 16 values, then across the 4 lane groups)
-            float mx = fmaxf(fmaxf(sc[0][qb][0], sc[0][qb][1]), fmaxf(sc[0][qb][2], sc[0][qb][3]));
-#pragma unroll
-            for (int kb = 1; kb < 4; ++kb)
-                mx = fmaxf(mx, fmaxf(fmaxf(sc[kb][qb][0], sc[kb][qb][1]), fmaxf(sc[kb][qb][2], sc[kb][qb][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float mx = max3f(sc[0][qb][0], sc[0][qb][1], sc[0][qb][2]);
+            mx = max3f(mx, sc[0][qb][3], sc[1][qb][0]);
+            mx = max3f(mx, sc[1][qb][1], sc[1][qb][2]);
+            mx = max3f(mx, sc[1][qb][3], sc[2][qb][0]);
+            mx = max3f(mx, sc[2][qb][1], sc[2][qb][2]);
+            mx = max3f(mx, sc[2][qb][3], sc[3][qb][0]);
+            mx = max3f(mx, sc[3][qb][1], sc[3][qb][2]);
+            mx = max3f(mx, sc[3][qb][3], sc[3][qb][3]);
+            {
+                const float o16 = __shfl_xor(mx, 16, 64);
+                mx = max3f(mx, o16, o16);
+                const float o32 = __shfl_xor(mx, 32, 64);
+                mx = max3f(mx, o32, o32);
+            }
             // deferred rescale (guide T13): keep the old running max while the new one is at most 2^DEFER larger in
             // the exp2 domain; P is then bounded by 2^DEFER (fp16 keeps full relative precision there) and the O^T
             // rescale + its accumulator traffic is skipped for the whole wave.
