@@ -33,7 +33,21 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
         const long rbase = (long)s * rows_per_stat;
         const int r0 = chunk * rows_per_chunk;
         const int r1 = min(r0 + rows_per_chunk, rows_per_stat);
-        for (int r = r0 + tr; r < r1; r += TR) {
+        int r = r0 + tr;
+        for (; r + 3 * TR < r1; r += 4 * TR) {
+            h8 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const h8*>(src + (rbase + r + q * TR) * cs + co);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[q][e];
+                    sum[e] += f;
+                    sq[e] += f * f;
+                }
+        }
+        for (; r < r1; r += TR) {
             h8 v = *reinterpret_cast<const h8*>(src + (rbase + r) * cs + co);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -107,7 +121,24 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ s1, const half_t* __r
     const long rbase = (long)s * rows_per_stat;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(r0 + rows_per_block, rows_per_stat);
-    for (int r = r0 + tr; r < r1; r += TR) {
+    int r = r0 + tr;
+    for (; r + 3 * TR < r1; r += 4 * TR) {          // 4 independent 16-byte loads in flight per thread
+        h8 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const h8*>(src + (rbase + r + q * TR) * cs + co);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = (float)v[q][e] * sc[e] + sh[e];
+                if (silu) y = silu_f(y);
+                o[e] = (half_t)y;
+            }
+            *reinterpret_cast<h8*>(out + (rbase + r + q * TR) * C + c0) = o;
+        }
+    }
+    for (; r < r1; r += TR) {
         h8 v = *reinterpret_cast<const h8*>(src + (rbase + r) * cs + co);
         h8 o;
 #pragma unroll
@@ -188,7 +219,7 @@ static int gn_geometry(int C, int* block) {
     return TR;
 }
 
-int uv_groupnorm_workspace_floats(int S, int G) { return S * 128 * G * 2; }
+int uv_groupnorm_workspace_floats(int S, int G) { return S * 129 * G * 2; }
 
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G,
                         float eps, const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part,
@@ -219,21 +250,23 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     const int rpb = (rows_per_stat + nblk - 1) / nblk;
     nblk = (rows_per_stat + rpb - 1) / rpb;
     long count_rows = rows_per_stat;
-    const float* stats = part;
-    int nch_apply = nchunk;
+    // reduce the chunk partials ONCE ([S,nchunk,G,2] -> [S,G,2], stored right behind them) instead of letting each of
+    // the ~2000 apply blocks walk all chunks serially (that prologue was ~1/2 of the apply kernel's time)
+    float* red = part + (size_t)S * nchunk * G * 2;
+    const int SG2 = S * G * 2;
+    if (comm && comm->world > 1) red = comm->red;
+    hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 255) / 256), dim3(256), 0, stream, part, red, nchunk, SG2, G * 2);
+    UV_LAUNCH_CHECK();
     if (comm && comm->world > 1) {     // frame shard: sum the partials over ranks (SURVEY §8e coupling 1)
-        const int SG2 = S * G * 2;
-        hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 255) / 256), dim3(256), 0, stream, part, comm->red, nchunk, SG2, G * 2);
-        UV_LAUNCH_CHECK();
         int rc = comm->allreduce(comm->user, comm->byte_off, SG2);
         if (rc) {
             uv_set_error("groupnorm: all-reduce callback failed (%d)", rc);
             return UV_ERR_STATE;
         }
-        stats = comm->red;
-        nch_apply = 1;
         count_rows = (long)rows_per_stat * comm->world;
     }
+    const float* stats = red;
+    const int nch_apply = 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, S), dim3(block), 2 * G * sizeof(float), stream, s1, s2, C1, C2,
                        rows_per_stat, rpb, G, nch_apply, eps, count_rows, stats, gamma, beta, silu, out);
     uv_prof_end(stream);
