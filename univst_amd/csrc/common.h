@@ -67,19 +67,19 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 // exact (erf) GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16 resolution): one
-// rcp + one exp2 + 6 fma instead of the ~40-instruction libm erff — the GEGLU epilogue runs it 250 M times per layer.
+// rcp + one exp2 + 8 fma/mul instead of the ~40-instruction libm erff — the GEGLU epilogue runs it 250 M times per
+// layer.  gelu(x) = 0.5*x*(1 + erf(x/sqrt2)) = 0.5*(x + |x| * erf(|x|/sqrt2))  (erf is odd), so no sign select.
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
     poly = fmaf(poly, t, 1.421413741f);
     poly = fmaf(poly, t, -0.284496736f);
     poly = fmaf(poly, t, 0.254829592f);
-    poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = 1.f - poly * e;
-    const float erfv = x < 0.f ? -erf_abs : erf_abs;
-    return 0.5f * x * (1.f + erfv);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    const float pe = poly * t * e;                    // 1 - erf(z)
+    return 0.5f * (x + fmaf(-ax, pe, ax));            // 0.5 * (x + |x| * (1 - pe))
 }
 
 // XCD-aware bijective block remap (8 XCDs, block b observed on XCD b%8): consecutive logical ids

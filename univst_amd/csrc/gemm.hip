@@ -43,11 +43,15 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                 const int ng = nx + 16;                     // gate rows
                 if (ng >= p.N) continue;
                 const int no = nb / 2 + (i / 2) * 16 + g * 4;
-                h4 o;
+                h4 o, bx = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+                if (p.bias) {
+                    bx = *reinterpret_cast<const h4*>(p.bias + nx);
+                    bg = *reinterpret_cast<const h4*>(p.bias + ng);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float xv = col[i][r] + (p.bias ? (float)p.bias[nx + r] : 0.f);
-                    float gv = col[i + 1][r] + (p.bias ? (float)p.bias[ng + r] : 0.f);
+                    float xv = col[i][r] + (float)bx[r];
+                    float gv = col[i + 1][r] + (float)bg[r];
                     o[r] = (half_t)(xv * gelu_erf_f(gv));
                 }
                 *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + no) = o;
