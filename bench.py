@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo stages through the host, bring-up only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--skip-dead-branches", action="store_true",
@@ -113,8 +114,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = min(local, torch.cuda.device_count() - 1)      # (bring-up: several ranks may share one GPU with --backend gloo)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -153,7 +158,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = tmax.item()
     assert torch.isfinite(lat.float()).all(), "non-finite latents"

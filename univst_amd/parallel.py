@@ -57,7 +57,8 @@ class FrameShard:
         if self.world == 1:
             return
         if self.comm is None:
-            self.comm = TorchDistComm()
+            import torch.distributed as dist
+            self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
         unet._sync_native()
         boc = unet.config.block_out_channels
         cmax = max_channels or max(boc)
@@ -156,6 +157,44 @@ class TorchDistComm:
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+
+
+class HostStagedDistComm(TorchDistComm):
+    """torch.distributed backend without device support for some ops (gloo): stage every payload through pinned host
+    memory.  Used to exercise the multi-process path on boxes where the ranks cannot each own a GPU (bring-up / CI);
+    production uses TorchDistComm over RCCL."""
+
+    def _cpu(self, t):
+        return t.detach().to("cpu")
+
+    def all_reduce_sum(self, t):
+        c = self._cpu(t)
+        self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM, group=self.group)
+        t.copy_(c)
+
+    def all_gather(self, t):
+        c = self._cpu(t)
+        outs = [torch.empty_like(c) for _ in range(self.world)]
+        self.dist.all_gather(outs, c, group=self.group)
+        return [o.to(t.device) for o in outs]
+
+    def halo_and_broadcast(self, send_last, first, recv_prev, recv_first):
+        dist, r, w = self.dist, self.rank, self.world
+        c = self._cpu(first if r == 0 else recv_first)
+        dist.broadcast(c, src=0, group=self.group)
+        if r > 0:
+            recv_first.copy_(c)
+        reqs = []
+        if r < w - 1:
+            reqs.append(dist.isend(self._cpu(send_last), r + 1, group=self.group))
+        rp = None
+        if r > 0:
+            rp = torch.empty(recv_prev.shape, dtype=recv_prev.dtype)
+            reqs.append(dist.irecv(rp, r - 1, group=self.group))
+        for q in reqs:
+            q.wait()
+        if rp is not None:
+            recv_prev.copy_(rp)
 
 
 class ThreadLoopbackComm:
