@@ -202,6 +202,17 @@ def main():
                            "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                            "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2),
                            "classes": classes}
+        # HBM traffic per launch of that kernel from the committed PMC passes (bench.py cannot collect PMCs itself):
+        # profiles/round1_pmc_traffic.json = rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this command
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))["kernels"]
+            key = dom.replace(" ", "")
+            hit = [v for k, v in pm.items() if key.split("<")[0] in k and key.split("<")[1].rstrip(">") in k.replace(" ", "")]
+            if hit and world == 1:
+                out["roofline"]["traffic"] = hit[0]["hbm_bytes_per_launch_corrected"]
+                out["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 PMC, gfx950-corrected, bytes/launch)"
+        except Exception:
+            pass
         tot_flops = sum(v["flops"] for v in prof.values()) / nprof
         out["config"]["algorithmic_tflop_per_step_executed"] = round(tot_flops / 1e12, 2)
         out["roofline"]["whole_step_tflops"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12, 1)

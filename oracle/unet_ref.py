@@ -255,7 +255,7 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample: torch.Tensor, t
     groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     lpb = cfg["layers_per_block"]
     B = sample.shape[0]
-    t = torch.as_tensor(timestep).reshape(-1).expand(B)
+    t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(B)
     t_emb = timestep_sinusoid(t, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"]).to(sample.dtype)
     emb = _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", t_emb)))
     ctx = encoder_hidden_states
