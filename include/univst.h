@@ -107,9 +107,13 @@ int univst_groupnorm_nhwc(const void* X1, const void* X2, int C1, int C2, int64_
 int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta, int64_t rows, int C, float eps,
                      void* stream);
 /* multi-source flash attention.  q rows (bf*Nq+i) at ldq, k/v rows (src*Nkv+j) at ldkv, src_idx int32 [BF][nsrc].
+ * Optional (may be NULL): src_cnt int32 [BF] = number of leading sources actually used for that frame, src_logw fp32
+ * [BF][nsrc] = log2 multiplicity of a source — a frame that occurs m times in the reference's concatenated key set
+ * ([prev, cur, first] at f = 0, 1) is read ONCE with log2(m) added to its scores, which is the same softmax.
  * Replaces attention.py:384-420, pnp_utils.py:59-92 and diffusers AttnProcessor2_0. */
 int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
-                     const int32_t* src_idx, int nsrc, int BF, int Nq, int Nkv, int heads, int head_dim, void* stream);
+                     const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv,
+                     int heads, int head_dim, void* stream);
 /* AdaIN-guided attention shift in place on the fused QKV buffer [3*F*N, 3C]; stats_ws: 4*F*2C floats.
  * Replaces pnp_utils.py:47-57 + attention_adain :114-125. */
 int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, float alpha, float beta, float gamma,

@@ -191,7 +191,7 @@ def sdpa_ref(q, k, v, heads):
     return unet_ref.sdpa(q.float(), k.float(), v.float(), heads)
 
 
-@pytest.mark.parametrize("heads,d,N,Fr,mode", [(2, 16, 64, 3, "stock"), (2, 32, 256, 4, "pnp"), (8, 40, 576, 2, "stock"),
+@pytest.mark.parametrize("heads,d,N,Fr,mode", [(2, 40, 2048 + 40, 2, "stock"), (8, 40, 2304, 1, "pnp"), (2, 16, 64, 3, "stock"), (2, 32, 256, 4, "pnp"), (8, 40, 576, 2, "stock"),
                                                 (8, 80, 128, 3, "pnp"), (8, 160, 64, 2, "stock"), (4, 64, 200, 2, "stock")])
 def test_attention_sparse_causal(nat, heads, d, N, Fr, mode):
     """fused-QKV layout, K/V gathered by pointer from {prev, (cur), first} frames of the same branch."""
@@ -210,6 +210,22 @@ def test_attention_sparse_causal(nat, heads, d, N, Fr, mode):
     src = torch.tensor(rows, dtype=torch.int32).cuda()
     got = nat.attention(q, k, v, src, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C)
     close(got, ref, rtol=4e-3)
+
+
+def test_attention_merged_duplicate_sources(nat):
+    """a source listed m times == the source once with log2(m) added to its scores (what the UNet graph does for the
+    duplicated frame 0 at f = 0, 1)."""
+    heads, d, N = 8, 40, 320
+    C = heads * d
+    qkv = rnd(3, N, 3 * C, seed=1)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    dup = torch.tensor([[0, 0, 0], [0, 1, 0], [1, 2, 0]], dtype=torch.int32).cuda()
+    ref = nat.attention(q, k, v, dup, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C)
+    uniq = torch.tensor([[0, 0, 0], [0, 1, 0], [1, 2, 0]], dtype=torch.int32).cuda()
+    cnt = torch.tensor([1, 2, 3], dtype=torch.int32).cuda()
+    lw = torch.tensor([[math.log2(3), 0, 0], [1.0, 0, 0], [0, 0, 0]], dtype=torch.float32).cuda()
+    got = nat.attention(q, k, v, uniq, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, src_cnt=cnt, src_logw=lw)
+    close(got, ref, rtol=2e-3)
 
 
 def test_attention_cross_77(nat):

@@ -134,9 +134,12 @@ int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta
     return uv_launch_layernorm(H(X), C, HM(Y), C, H(gamma), H(beta), rows, C, eps, S(s));
 }
 int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
-                     const int32_t* src_idx, int nsrc, int BF, int Nq, int Nkv, int heads, int d, void* s) {
+                     const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv, int heads,
+                     int d, void* s) {
     UV_REQUIRE(q && k && v && out && src_idx, "attention: null argument");
     AttnParams a;
+    a.src_cnt = src_cnt;
+    a.src_logw = src_logw;
     a.q = H(q); a.k = H(k); a.v = H(v); a.o = HM(out); a.ldq = ldq; a.ldkv = ldkv; a.ldo = ldo; a.src_idx = src_idx; a.nsrc = nsrc;
     a.BF = BF; a.Nq = Nq; a.Nkv = Nkv; a.heads = heads; a.d = d;
     a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);

@@ -13,6 +13,8 @@
 // Replaces: attention.py:384-420 (SparseCausalAttention gather + SDPA), pnp_utils.py:59-92 (PnP gather +
 // SDPA), diffusers AttnProcessor2_0 SDPA for attn2.
 #include "common.h"
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace {
@@ -81,7 +83,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     }
 
     const int ntile = (p.Nkv + KT - 1) / KT;
-    const int T = p.nsrc * ntile;
+    const int T = (p.src_cnt ? p.src_cnt[bf] : p.nsrc) * ntile;
     h8 kr[NKL], vr[NVL];
     // per-thread staging geometry is tile-invariant: element offsets inside a [64-key] tile and validity of the chunk
     unsigned koff[NKL], voff[NVL];
@@ -156,6 +158,8 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
         half_t* Vs = Ks + KT * KSTR;
         if (tt + 1 < T) load_tile(tt + 1);
         const int t0 = (tt % ntile) * KT;
+        const float lw = p.src_logw ? p.src_logw[bf * p.nsrc + tt / ntile] : 0.f;    // log2 multiplicity of this source
+        const float lwr = lw * (1.f / c);                                               // ... in raw-score units
 
         // ---- S^T = K Q^T
         f4 sc[4][QB];
@@ -203,6 +207,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
             // deferred rescale (guide T13): keep the old running max while the new one is at most 2^DEFER larger in
             // the exp2 domain; P is then bounded by 2^DEFER (fp16 keeps full relative precision there) and the O^T
             // rescale + its accumulator traffic is skipped for the whole wave.
+            mx += lwr;
             float alpha = 1.f;
             if (__builtin_amdgcn_ballot_w64((mx - mrun[qb]) * c > DEFER) != 0) {
                 const float mnew = fmaxf(mrun[qb], mx);
@@ -214,7 +219,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
                 }
                 if (!ONES) lrun[qb] *= alpha;
             }
-            const float mc = -mrun[qb] * c;
+            const float mc = fmaf(-mrun[qb], c, lw);
             if (ONES) {
                 union { fh2 h[4]; h8 v; } u0, u1;
 #pragma unroll
@@ -314,8 +319,22 @@ __global__ void tr16_probe_kernel(float* out) {
     for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (float)v[j];
 }
 
+template <int DPAD, int DV16, int QB>
+__global__ __launch_bounds__(256, 2) void attn_kernel_occ2(AttnParams p) {
+    attn_body<DPAD, DV16, QB>(p);
+}
+
 template <int DPAD, int DV16>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
+    static const int qb4 = getenv("UNIVST_ATTN_QB4") ? atoi(getenv("UNIVST_ATTN_QB4")) : 1;   // 64 query rows per wave for long sequences
+    if constexpr (DPAD <= 64) {
+        if (qb4 && p.Nq >= 2048) {
+            const int nqb4 = (p.Nq + 255) / 256;
+            hipLaunchKernelGGL((attn_kernel_occ2<DPAD, DV16, 4>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
     const int QB = p.Nq >= 512 ? 2 : 1;
     const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
     dim3 grid(nqb * p.heads * p.BF), block(256);

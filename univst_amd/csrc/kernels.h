@@ -33,6 +33,9 @@ struct AttnParams {
     half_t* o = nullptr;
     long ldq = 0, ldkv = 0, ldo = 0;
     const int* src_idx = nullptr;   // [BF][nsrc] source frame (row-block) of every key segment
+    const int* src_cnt = nullptr;   // optional [BF]: only the first src_cnt[bf] sources are used
+    const float* src_logw = nullptr;  // optional [BF][nsrc]: log2 multiplicity of a source (duplicate frames merged: softmax over a
+                                      // key set that contains frame X m times == adding log2(m) to X's scores)
     int nsrc = 1, BF = 0, Nq = 0, Nkv = 0, heads = 0, d = 0;
     float scale_log2e = 0.f;
 };

@@ -286,19 +286,40 @@ int UNet::reserve(int B, int F, int H, int Wd) {
         const bool ext = world > 1 && rank > 0;
         auto prev = [&](int b, int f) { return f > 0 ? b * F + f - 1 : (ext ? B * F + b : b * F); };
         auto first = [&](int b) { return ext ? B * F + B + b : b * F; };
-        for (int b = 0; b < B; ++b)
-            for (int f = 0; f < F; ++f) {   // stock: [-1, 0, 'first'] (attention.py:356)
-                t.push_back(prev(b, f));
-                t.push_back(b * F + f);
-                t.push_back(first(b));
+        // Duplicate sources are merged: at f = 0 the reference's key set is {0,0,0} (stock) / {0,0} (PnP), at f = 1 it is
+        // {0,1,0} / {0,0}.  Softmax over a key set that contains frame X m times equals reading X once with log2(m) added
+        // to its scores, so the table keeps unique sources + (count, log2 multiplicity) — exact, 6 % fewer key tiles.
+        std::vector<int> cnt;
+        std::vector<float> lw;
+        auto emit = [&](std::vector<int> srcs, int width) {
+            std::vector<int> uniq;
+            std::vector<int> mult;
+            for (int sidx : srcs) {
+                size_t j = 0;
+                for (; j < uniq.size(); ++j)
+                    if (uniq[j] == sidx) break;
+                if (j == uniq.size()) { uniq.push_back(sidx); mult.push_back(1); }
+                else mult[j]++;
             }
-        for (int b = 0; b < B; ++b)
-            for (int f = 0; f < F; ++f) {   // PnP: [-1, 'first'] (pnp_utils.py:25)
-                t.push_back(prev(b, f));
-                t.push_back(first(b));
+            cnt.push_back((int)uniq.size());
+            for (int j = 0; j < width; ++j) {
+                t.push_back(j < (int)uniq.size() ? uniq[j] : uniq[0]);
+                lw.push_back(j < (int)uniq.size() ? log2f((float)mult[j]) : 0.f);
             }
+        };
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < F; ++f) emit({prev(b, f), b * F + f, first(b)}, 3);   // stock: [-1, 0, 'first'] (attention.py:356)
+        for (int b = 0; b < B; ++b)
+            for (int f = 0; f < F; ++f) emit({prev(b, f), first(b)}, 2);              // PnP: [-1, 'first'] (pnp_utils.py:25)
         for (int b = 0; b < B; ++b)
             for (int f = 0; f < F; ++f) t.push_back(b);   // text: one [77, C] block per branch
+        // layout of the device table: [idx stock 3BF | idx pnp 2BF | idx text BF | cnt stock BF | cnt pnp BF | logw stock 3BF | logw pnp 2BF]
+        for (int v : cnt) t.push_back(v);
+        for (float v : lw) {
+            int bits;
+            memcpy(&bits, &v, 4);
+            t.push_back(bits);
+        }
         int* d;
         UV_HIP(hipMalloc(&d, t.size() * sizeof(int)));
         UV_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -321,7 +342,8 @@ struct Fwd {
     const univst_pnp_t* pnp;
     half_t* emb = nullptr;     // [B, 4*C0]
     const half_t* text = nullptr;
-    const int *idx_stock = nullptr, *idx_pnp = nullptr, *idx_text = nullptr;
+    const int *idx_stock = nullptr, *idx_pnp = nullptr, *idx_text = nullptr, *cnt_stock = nullptr, *cnt_pnp = nullptr;
+    const float *lw_stock = nullptr, *lw_pnp = nullptr;
     float* gn_ws = nullptr;
     float* ad_ws = nullptr;
 
@@ -492,6 +514,8 @@ struct Fwd {
         ap.ldq = ap.ldkv = 3 * C;
         ap.o = t0; ap.ldo = C;
         ap.src_idx = registered ? idx_pnp : idx_stock;
+        ap.src_cnt = registered ? cnt_pnp : cnt_stock;
+        ap.src_logw = registered ? lw_pnp : lw_stock;
         ap.nsrc = registered ? 2 : 3;
         ap.BF = x.imgs; ap.Nq = N; ap.Nkv = N; ap.heads = heads; ap.d = d;
         ap.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
@@ -514,7 +538,7 @@ struct Fwd {
         ap.q = q2; ap.ldq = C;
         ap.k = kv; ap.v = kv + C; ap.ldkv = 2 * C;
         ap.o = t0; ap.ldo = C;
-        ap.src_idx = idx_text; ap.nsrc = 1; ap.Nkv = text_len;
+        ap.src_idx = idx_text; ap.src_cnt = nullptr; ap.src_logw = nullptr; ap.nsrc = 1; ap.Nkv = text_len;
         RUN(uv_launch_attention(ap, s));
         free(q2);
         free(kv);
@@ -564,9 +588,14 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     Fwd f{*this, s, B, F, text_len, pnp};
     f.text = text;
     const int* tab = idx_tables[((long)B << 20) | F | ((long)rank << 40) | ((long)world << 50)];
+    const long BF_ = (long)B * F;
     f.idx_stock = tab;
-    f.idx_pnp = tab + (long)B * F * 3;
-    f.idx_text = tab + (long)B * F * 5;
+    f.idx_pnp = tab + BF_ * 3;
+    f.idx_text = tab + BF_ * 5;
+    f.cnt_stock = tab + BF_ * 6;
+    f.cnt_pnp = tab + BF_ * 7;
+    f.lw_stock = (const float*)(tab + BF_ * 8);
+    f.lw_pnp = (const float*)(tab + BF_ * 11);
     f.gn_ws = (float*)arena.alloc((size_t)uv_groupnorm_workspace_floats(B * F, cfg.norm_num_groups) * sizeof(float));
     f.ad_ws = (float*)arena.alloc((size_t)F * 2 * boc[3] * 2 * sizeof(float) + 1024);
     UV_REQUIRE(f.gn_ws && f.ad_ws, "forward: arena too small");
