@@ -106,13 +106,14 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
     }
 }
 
-constexpr int BM = 128;
+constexpr int BM_DEFAULT = 128;
 
 // BK: k extent of one LDS tile (32 or 64).  DBUF: two LDS buffers -> one barrier per k tile, the next tile's global
 // loads stay in flight under the MFMAs and are written to the other buffer right after them.
-template <int NF, int MODE, int BK, bool DBUF, int OCC = 2, int ABL = 0, bool GLDS = false>
+template <int NF, int MODE, int BK, bool DBUF, int OCC = 2, int ABL = 0, bool GLDS = false, int MF = 4>
 __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
     constexpr int BN = NF * 32;
+    constexpr int BM = 32 * MF;          // MF = 4: 128-row tile; MF = 2: 64-row tile for small-M problems that would leave CUs idle
     // register-staged path: rows padded (80 halfs for BK 64 / 48 for BK 32) -> conflict-free b128 reads.
     // GLDS path: global_load_lds writes lane-linear 16-byte pieces, so rows are UNPADDED 128 B and the 16-byte chunk
     // index is XOR-swizzled with (row & 7) — applied to the per-lane SOURCE address and to the fragment reads.
@@ -252,11 +253,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < WL; ++i) glds16((w_ok[i] && kok) ? wptr[i] + k0 : uv_zero_page, Wd + RPP * i * LDSH);
     };
 
-    f4 acc[NF][4];
+    f4 acc[NF][MF];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (p.K + BK - 1) / BK;
     if (GLDS) {
@@ -284,17 +285,17 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
-            h8 a[NF], b[4];
+            h8 a[NF], b[MF];
 #pragma unroll
             for (int i = 0; i < NF; ++i)
                 a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * NF * 16 + i * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                b[j] = *reinterpret_cast<const h8*>(&Xs[(wm * 64 + j * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
+            for (int j = 0; j < MF; ++j)
+                b[j] = *reinterpret_cast<const h8*>(&Xs[(wm * 16 * MF + j * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
 #pragma unroll
             for (int i = 0; i < NF; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < MF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (GLDS) {
@@ -312,11 +313,11 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
 
     // ---- epilogue: lane holds rows n = nb + g*4 + r (r<4) of column m = mb + l15
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < MF; ++j) {
         f4 col[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
-        gemm_epilogue_row<NF>(p, col, m0 + wm * 64 + j * 16 + l15, n0 + wn * NF * 16, g);
+        gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MF + j * 16 + l15, n0 + wn * NF * 16, g);
     }
 }
 
@@ -488,6 +489,18 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const half_t* __restr
 
 }  // namespace
 
+static int uv_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        n = 256;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            n = pr.multiProcessorCount;
+    }
+    return n;
+}
+
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
@@ -519,7 +532,10 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     }
     bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0) && (variant0 < 3 || variant0 == 5);
     int BN = nf5 ? 160 : 128;
-    int nt = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    int nt = ((p.M + BM_DEFAULT - 1) / BM_DEFAULT) * ((p.N + BN - 1) / BN);
+    // small-M problems (deepest UNet level: 3072 rows): 64-row tiles double the block count so the chip is filled
+    const bool small_m = variant0 == 5 && !nf5 && nt < 2 * uv_num_cus() && p.M > 64;
+    if (small_m) nt = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
     dim3 grid(nt), block(256);
     static const int variant = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
@@ -535,7 +551,10 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_>), grid, block, 0, stream, p);        \
         }                                                                                             \
     } while (0)
-    if (variant == 5) {
+    if (variant == 5 && small_m) {
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, 0, true, 2>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 2, 0, true, 2>), grid, block, 0, stream, p);
+    } else if (variant == 5) {
         if (mode == 0) {
             if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, 64, false, 2, 0, true>), grid, block, 0, stream, p);
             else hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, 0, true>), grid, block, 0, stream, p);
