@@ -110,8 +110,8 @@ constexpr int BM_DEFAULT = 128;
 
 // BK: k extent of one LDS tile (32 or 64).  DBUF: two LDS buffers -> one barrier per k tile, the next tile's global
 // loads stay in flight under the MFMAs and are written to the other buffer right after them.
-template <int NF, int MODE, int BK, bool DBUF, int OCC = 2, int ABL = 0, bool GLDS = false, int MF = 4>
-__global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
+template <int NF, int MODE, int BK, bool DBUF, bool GLDS, int MF = 4>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     constexpr int BN = NF * 32;
     constexpr int BM = 32 * MF;          // MF = 4: 128-row tile; MF = 2: 64-row tile for small-M problems that would leave CUs idle
     // register-staged path: rows padded (80 halfs for BK 64 / 48 for BK 32) -> conflict-free b128 reads.
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
                 issue_tile((kt + 1) * BK, (kt + 1) & 1);
                 advance_k();
             }
-        } else if (kt + 1 < nk && ABL != 2 && ABL != 3) {                 // next tile's global loads fly under this tile's MFMAs
+        } else if (kt + 1 < nk) {                 // next tile's global loads fly under this tile's MFMAs
             load_tile((kt + 1) * BK);
             advance_k();
         }
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_kernel(GemmParams p) {
             if (kt + 1 < nk) store_tile((kt + 1) & 1);
             __syncthreads();
         } else {
-            if (ABL != 4) __syncthreads();
-            if (kt + 1 < nk && ABL != 1 && ABL != 3 && ABL != 4) {
+            __syncthreads();
+            if (kt + 1 < nk) {
                 store_tile(0);
                 __syncthreads();
             }
@@ -530,7 +530,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             return UV_OK;
         }
     }
-    bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0) && (variant0 < 3 || variant0 == 5);
+    bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0) ;
     int BN = nf5 ? 160 : 128;
     int nt = ((p.M + BM_DEFAULT - 1) / BM_DEFAULT) * ((p.N + BN - 1) / BN);
     // small-M problems (deepest UNet level: 3072 rows): 64-row tiles double the block count so the chip is filled
@@ -541,39 +541,24 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     static const int variant = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
                   2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
-#define UV_GEMM_LAUNCH(BK_, DB_)                                                                      \
-    do {                                                                                              \
-        if (mode == 0) {                                                                              \
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, BK_, DB_>), grid, block, 0, stream, p);    \
-            else hipLaunchKernelGGL((gemm_kernel<4, 0, BK_, DB_>), grid, block, 0, stream, p);        \
-        } else {                                                                                      \
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, BK_, DB_>), grid, block, 0, stream, p);    \
-            else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_>), grid, block, 0, stream, p);        \
-        }                                                                                             \
+#define UV_GEMM_LAUNCH(BK_, DB_, GL_)                                                                       \
+    do {                                                                                                   \
+        if (mode == 0) {                                                                                   \
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, BK_, DB_, GL_>), grid, block, 0, stream, p);    \
+            else hipLaunchKernelGGL((gemm_kernel<4, 0, BK_, DB_, GL_>), grid, block, 0, stream, p);        \
+        } else {                                                                                           \
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, BK_, DB_, GL_>), grid, block, 0, stream, p);    \
+            else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_, GL_>), grid, block, 0, stream, p);        \
+        }                                                                                                  \
     } while (0)
+    // UNIVST_GEMM_VARIANT (A/B aid): 5 = global_load_lds staging (default); 0 = register-staged, one LDS buffer;
+    // 1 = register-staged, two LDS buffers.  The DMA path won every shape except none (tools/bench_gemm.py).
     if (variant == 5 && small_m) {
-        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, 0, true, 2>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 2, 0, true, 2>), grid, block, 0, stream, p);
-    } else if (variant == 5) {
-        if (mode == 0) {
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, 64, false, 2, 0, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, 0, true>), grid, block, 0, stream, p);
-        } else {
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, 64, false, 2, 0, true>), grid, block, 0, stream, p);
-            else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 2, 0, true>), grid, block, 0, stream, p);
-        }
-    } else if (variant >= 11 && variant <= 14) {   // ablations (wrong results): 11 no LDS stores, 12 no global loads, 13 neither, 14 + no barriers
-#define UV_ABL(A_) do { if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 2, A_>), grid, block, 0, stream, p); else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 2, A_>), grid, block, 0, stream, p); } while (0)
-        if (variant == 11) UV_ABL(1); else if (variant == 12) UV_ABL(2); else if (variant == 13) UV_ABL(3); else UV_ABL(4);
-    } else if (variant == 3) {
-        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 4>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 4>), grid, block, 0, stream, p);
-    } else if (variant == 4) {
-        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, 3>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, 3>), grid, block, 0, stream, p);
-    } else if (variant == 1) UV_GEMM_LAUNCH(64, true);
-    else if (variant == 2) UV_GEMM_LAUNCH(32, true);
-    else UV_GEMM_LAUNCH(64, false);
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, true, 2>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, true, 2>), grid, block, 0, stream, p);
+    } else if (variant == 5) UV_GEMM_LAUNCH(64, false, true);
+    else if (variant == 1) UV_GEMM_LAUNCH(64, true, false);
+    else UV_GEMM_LAUNCH(64, false, false);
     uv_prof_end(stream);
     UV_LAUNCH_CHECK();
     return UV_OK;
