@@ -39,7 +39,8 @@ typedef struct {
     int block_out_channels[4];
     int layers_per_block;
     int cross_attention_dim;
-    int attention_heads;        /* SD config key attention_head_dim, used as HEAD COUNT (unet_3d_blocks.py:269-271) */
+    int attention_heads[4];     /* SD config key attention_head_dim per down level, used as HEAD COUNT (unet_3d_blocks.py:269-271);
+                                   SD-v1.x: 8,8,8,8 (head_dim = C/8); SD-v2.x: 5,10,20,20 (head_dim 64) */
     int norm_num_groups;
     float norm_eps;
     int flip_sin_to_cos;

@@ -35,6 +35,8 @@ SD15_CONFIG = dict(
 
 TINY_CONFIG = dict(SD15_CONFIG, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
                    cross_attention_dim=32, attention_head_dim=2, norm_num_groups=8)
+# SD-v2.x shaped tiny config: Linear proj_in/out, per-level head counts (head_dim 16/32), wider text dim
+TINY_SD2_CONFIG = dict(TINY_CONFIG, use_linear_projection=True, attention_head_dim=(2, 2, 4, 4), cross_attention_dim=64)
 
 # pnp_utils.py:104-111 — the 8 injected attn1 layers: {up_block: [attention indices]}
 PNP_LAYERS = {1: [1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}
@@ -222,11 +224,18 @@ def transformer_model(sd, p, x, ctx, heads, groups, pnp, exact_temporal=True):
     ctx = ctx.repeat_interleave(f, 0)
     res = y
     y = F.group_norm(y, groups, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)    # per frame, eps 1e-6
-    y = F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
-    y = y.permute(0, 2, 3, 1).reshape(b * f, h * w, c)
+    lin = sd[p + ".proj_in.weight"].dim() == 2        # use_linear_projection (SD-v2.x): attention.py:125-127,142-144
+    if lin:
+        y = F.linear(y.permute(0, 2, 3, 1).reshape(b * f, h * w, c), sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    else:
+        y = F.conv2d(y, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+        y = y.permute(0, 2, 3, 1).reshape(b * f, h * w, c)
     y = transformer_block(sd, p + ".transformer_blocks.0", y, ctx, f, heads, pnp, exact_temporal)
-    y = y.view(b * f, h, w, c).permute(0, 3, 1, 2)
-    y = F.conv2d(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]) + res
+    if lin:
+        y = F.linear(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]).view(b * f, h, w, c).permute(0, 3, 1, 2) + res
+    else:
+        y = y.view(b * f, h, w, c).permute(0, 3, 1, 2)
+        y = F.conv2d(y, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]) + res
     return y.view(b, f, c, h, w).permute(0, 2, 1, 3, 4).contiguous()
 
 
@@ -251,7 +260,8 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample: torch.Tensor, t
     unet_3d_condition.py:430-436).
     """
     boc = cfg["block_out_channels"]
-    heads = cfg["attention_head_dim"]
+    hd = cfg["attention_head_dim"]
+    hl = (hd,) * 4 if isinstance(hd, int) else tuple(hd)          # head COUNT per down level (unet_3d_condition.py:118-119)
     groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     lpb = cfg["layers_per_block"]
     B = sample.shape[0]
@@ -272,13 +282,13 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample: torch.Tensor, t
         for j in range(lpb):
             x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, groups, eps, exact_temporal)
             if bt.startswith("CrossAttn"):
-                x = transformer_model(sd, f"{p}.attentions.{j}", x, ctx, heads, groups, None, exact_temporal)
+                x = transformer_model(sd, f"{p}.attentions.{j}", x, ctx, hl[i], groups, None, exact_temporal)
             skips.append(x)
         if i != len(boc) - 1:
             x = pseudo_conv3d(sd, f"{p}.downsamplers.0.conv", x, stride=2, exact_temporal=exact_temporal)
             skips.append(x)
     x = resnet_block(sd, "mid_block.resnets.0", x, emb, groups, eps, exact_temporal)
-    x = transformer_model(sd, "mid_block.attentions.0", x, ctx, heads, groups, None, exact_temporal)
+    x = transformer_model(sd, "mid_block.attentions.0", x, ctx, hl[-1], groups, None, exact_temporal)
     x = resnet_block(sd, "mid_block.resnets.1", x, emb, groups, eps, exact_temporal)
     feats = {}
     for i, bt in enumerate(cfg["up_block_types"]):
@@ -287,7 +297,7 @@ def unet_forward(sd: Dict[str, torch.Tensor], cfg: dict, sample: torch.Tensor, t
             x = torch.cat([x, skips.pop()], dim=1)
             x = resnet_block(sd, f"{p}.resnets.{j}", x, emb, groups, eps, exact_temporal)
             if bt.startswith("CrossAttn"):
-                x = transformer_model(sd, f"{p}.attentions.{j}", x, ctx, heads, groups, pnp_for(i, j),
+                x = transformer_model(sd, f"{p}.attentions.{j}", x, ctx, hl[len(boc) - 1 - i], groups, pnp_for(i, j),
                                       exact_temporal)
         if i != len(boc) - 1:
             x = upsample(sd, f"{p}.upsamplers.0", x, exact_temporal)
@@ -342,13 +352,17 @@ def state_dict_shapes(cfg: dict) -> Dict[str, tuple]:
 
     def tr(p, c):
         norm(p + ".norm", c)
-        conv(p + ".proj_in", c, c, 1)
+        if cfg.get("use_linear_projection"):
+            lin(p + ".proj_in", c, c)
+            lin(p + ".proj_out", c, c)
+        else:
+            conv(p + ".proj_in", c, c, 1)
+            conv(p + ".proj_out", c, c, 1)
         b = p + ".transformer_blocks.0"
         attn(b + ".attn1", c, c); norm(b + ".norm1", c)
         attn(b + ".attn2", c, D); norm(b + ".norm2", c)
         attn(b + ".attn_temporal", c, c); norm(b + ".norm_temporal", c)
         lin(b + ".ff.net.0.proj", c, 8 * c); lin(b + ".ff.net.2", 4 * c, c); norm(b + ".norm3", c)
-        conv(p + ".proj_out", c, c, 1)
 
     conv("conv_in", cfg["in_channels"], boc[0], 3)
     lin("time_embedding.linear_1", boc[0], ted)

@@ -24,9 +24,12 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 def plant_environment():
     import transformers  # noqa: F401  (must be imported BEFORE the empty torchvision stub is planted)
     from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401
+    # order matters: the repo root also carries drop-in shims named like the reference's namespace packages
+    # (backbones/, src/, inversion_tools/); the REFERENCE must win here, so it goes first.
+    sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+    sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle", "_stubs"))
     sys.path.insert(0, REF)
-    sys.path.insert(0, ROOT)
     from PIL import Image
 
     def mod(name, **attrs):
@@ -64,6 +67,8 @@ def build_reference_unet(cfg, sd):
     from backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel
     kw = {k: cfg[k] for k in ("in_channels", "out_channels", "block_out_channels", "layers_per_block",
                               "cross_attention_dim", "attention_head_dim", "norm_num_groups", "norm_eps")}
+    if cfg.get("use_linear_projection"):
+        kw["use_linear_projection"] = True
     unet = UNetPseudo3DConditionModel(sample_size=64, **kw)   # SD-v1.5 config.json has sample_size 64
     missing = set(unet.state_dict().keys()) ^ set(sd.keys())
     assert not missing, f"state-dict key mismatch: {sorted(missing)[:5]}"
@@ -159,6 +164,21 @@ def main():
                 o_fast, _ = unet_ref.unet_forward(sd, cfg, x, t, ctx, pnp_idx=idx, exact_temporal=False)
                 chk(f"unet_{tag}_pnp{idx}_fast", eps, o_fast)
             gold[f"g5_{tag}_pnp{idx}"] = dict(t=t, eps=eps)
+
+    # ---- G11: SD-v2.x shaped tiny config (Linear proj_in/out, per-level head counts) — SURVEY §8f-3
+    cfg2 = unet_ref.TINY_SD2_CONFIG
+    sd2 = unet_ref.synth_state_dict(cfg2, seed=33)
+    unet2 = build_reference_unet(cfg2, sd2)
+    pipe2 = types.SimpleNamespace(unet=unet2)
+    x2 = torch.cat([si.content_latent(50, 4, 16, 16), si.style_latent(50, 4, 16, 16), si.content_latent(49, 4, 16, 16)])
+    ctx2 = si.text_embedding(cfg2["cross_attention_dim"]).expand(3, -1, -1).contiguous()
+    e_single = unet2(x2[:1], 301, encoder_hidden_states=ctx2[:1]).sample
+    chk("unet_sd2_single", e_single, unet_ref.unet_forward(sd2, cfg2, x2[:1], 301, ctx2[:1], None)[0])
+    ref_pnp.register_spatial_attention_pnp(pipe2)
+    ref_pnp.register_time(pipe2, 10)
+    e_pnp = unet2(x2, 781, encoder_hidden_states=ctx2).sample
+    chk("unet_sd2_pnp10", e_pnp, unet_ref.unet_forward(sd2, cfg2, x2, 781, ctx2, pnp_idx=10)[0])
+    gold["g11_sd2"] = dict(single=e_single, pnp10=e_pnp)
 
     # ---- G6: seeded init of the never-loaded *_temporal* parameters (construction-order pin; SURVEY "hard parts")
     from src.util import seed_everything

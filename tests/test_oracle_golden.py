@@ -107,3 +107,13 @@ def test_transfer_loop(golden, tag):
             callback=lambda i, t, l: got.__setitem__(i, l.clone()) if i in keep else None)
     for i in keep:
         assert rel(got[i], g[f"i{i}"]) < 2e-3, i
+
+
+def test_sd2_shaped_unet(golden):
+    cfg = unet_ref.TINY_SD2_CONFIG
+    sd = unet_ref.synth_state_dict(cfg, seed=33)
+    x = torch.cat([si.content_latent(50, 4, 16, 16), si.style_latent(50, 4, 16, 16), si.content_latent(49, 4, 16, 16)])
+    ctx = si.text_embedding(cfg["cross_attention_dim"]).expand(3, -1, -1).contiguous()
+    g = golden("g11_sd2")
+    assert rel(unet_ref.unet_forward(sd, cfg, x[:1], 301, ctx[:1], None)[0], g["single"]) < TOL
+    assert rel(unet_ref.unet_forward(sd, cfg, x, 781, ctx, pnp_idx=10)[0], g["pnp10"]) < TOL

@@ -15,7 +15,7 @@ _lib = None
 
 class UnetCfg(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("block_out_channels", C.c_int * 4),
-                ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int), ("attention_heads", C.c_int),
+                ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int), ("attention_heads", C.c_int * 4),
                 ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("flip_sin_to_cos", C.c_int),
                 ("freq_shift", C.c_float)]
 

@@ -111,15 +111,17 @@ class SpatioTemporalTransformerBlock(_ParamOnly):
 
 
 class SpatioTemporalTransformerModel(_ParamOnly):
-    """attention.py:40-102 (ctor, use_linear_projection=False)."""
+    """attention.py:40-102 (ctor; 1x1-conv projections for SD-v1.x, Linear for SD-v2.x use_linear_projection)."""
+    use_linear_projection = False
 
     def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups):
         super().__init__()
         inner = heads * dim_head
+        lin = SpatioTemporalTransformerModel.use_linear_projection
         self.norm = nn.GroupNorm(num_groups=groups, num_channels=in_channels, eps=1e-6, affine=True)
-        self.proj_in = nn.Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
+        self.proj_in = nn.Linear(in_channels, inner) if lin else nn.Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
         self.transformer_blocks = nn.ModuleList([SpatioTemporalTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
-        self.proj_out = nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0)
+        self.proj_out = nn.Linear(in_channels, inner) if lin else nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0)
 
 
 class DownsamplePseudo3D(_ParamOnly):
@@ -249,10 +251,6 @@ class UNetPseudo3DConditionModel(nn.Module):
         unsupported = []
         if tuple(down_block_types) != _DOWN or tuple(up_block_types) != _UP:
             unsupported.append("block types other than the SD-v1.x layout")
-        if use_linear_projection:
-            unsupported.append("use_linear_projection=True (SD-v2.x)")
-        if not isinstance(attention_head_dim, int):
-            unsupported.append("per-level attention_head_dim")
         if class_embed_type is not None or num_class_embeds is not None:
             unsupported.append("class embeddings")
         if center_input_sample or dual_cross_attention or only_cross_attention or resnet_time_scale_shift != "default":
@@ -264,7 +262,12 @@ class UNetPseudo3DConditionModel(nn.Module):
         if unsupported:
             raise NotImplementedError("univst_amd native UNet does not implement: " + "; ".join(unsupported))
 
-        boc, heads, groups, eps, xdim = block_out_channels, attention_head_dim, norm_num_groups, norm_eps, cross_attention_dim
+        boc, groups, eps, xdim = block_out_channels, norm_num_groups, norm_eps, cross_attention_dim
+        hl = (attention_head_dim,) * 4 if isinstance(attention_head_dim, int) else tuple(attention_head_dim)     # head COUNT per level
+        if len(hl) != 4:
+            raise NotImplementedError("attention_head_dim must be an int or a 4-tuple")
+        self._heads_per_level = hl
+        SpatioTemporalTransformerModel.use_linear_projection = bool(use_linear_projection)
         ted = boc[0] * 4
         self.sample_size = sample_size
         self.conv_in = PseudoConv3d(in_channels, boc[0], kernel_size=3, padding=(1, 1))
@@ -279,9 +282,9 @@ class UNetPseudo3DConditionModel(nn.Module):
             if bt == "DownBlockPseudo3D":
                 blk = DownBlockPseudo3D(in_c, out_c, ted, layers_per_block, groups, eps, not final)
             else:
-                blk = CrossAttnDownBlockPseudo3D(in_c, out_c, ted, layers_per_block, groups, eps, heads, xdim, not final)
+                blk = CrossAttnDownBlockPseudo3D(in_c, out_c, ted, layers_per_block, groups, eps, hl[i], xdim, not final)
             self.down_blocks.append(blk)
-        self.mid_block = UNetMidBlockPseudo3DCrossAttn(boc[-1], ted, groups, eps, heads, xdim)
+        self.mid_block = UNetMidBlockPseudo3DCrossAttn(boc[-1], ted, groups, eps, hl[-1], xdim)
         self.num_upsamplers = 0
         rev = list(reversed(boc))
         out_c = rev[0]
@@ -294,8 +297,9 @@ class UNetPseudo3DConditionModel(nn.Module):
             if bt == "UpBlockPseudo3D":
                 blk = UpBlockPseudo3D(in_c, out_c, prev_c, ted, layers_per_block + 1, groups, eps, not final)
             else:
-                blk = CrossAttnUpBlockPseudo3D(in_c, out_c, prev_c, ted, layers_per_block + 1, groups, eps, heads, xdim, not final)
+                blk = CrossAttnUpBlockPseudo3D(in_c, out_c, prev_c, ted, layers_per_block + 1, groups, eps, hl[len(boc) - 1 - i], xdim, not final)
             self.up_blocks.append(blk)
+        SpatioTemporalTransformerModel.use_linear_projection = False
         self.conv_norm_out = nn.GroupNorm(num_channels=boc[0], num_groups=groups, eps=eps)
         self.conv_act = nn.SiLU()
         self.conv_out = PseudoConv3d(boc[0], out_channels, kernel_size=3, padding=1)
@@ -345,7 +349,7 @@ class UNetPseudo3DConditionModel(nn.Module):
             self._native_handle = None
         c = self.config
         cfg = _native.UnetCfg(c.in_channels, c.out_channels, (C.c_int * 4)(*c.block_out_channels), c.layers_per_block,
-                              c.cross_attention_dim, c.attention_head_dim, c.norm_num_groups, c.norm_eps,
+                              c.cross_attention_dim, (C.c_int * 4)(*self._heads_per_level), c.norm_num_groups, c.norm_eps,
                               int(c.flip_sin_to_cos), float(c.freq_shift))
         h = C.c_void_p()
         _native.check(lib.univst_unet_create(C.byref(cfg), C.byref(h)), "unet_create")

@@ -32,10 +32,11 @@ int univst_abi_version(void) { return 1; }
 
 int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     UV_REQUIRE(cfg && out, "unet_create: null argument");
-    UV_REQUIRE(cfg->attention_heads > 0 && cfg->norm_num_groups > 0 && cfg->layers_per_block > 0, "unet_create: bad config");
+    UV_REQUIRE(cfg->norm_num_groups > 0 && cfg->layers_per_block > 0, "unet_create: bad config");
     for (int i = 0; i < 4; ++i) {
         int c = cfg->block_out_channels[i];
-        UV_REQUIRE(c % 8 == 0 && c % cfg->norm_num_groups == 0 && c % cfg->attention_heads == 0 && (c / cfg->attention_heads) % 8 == 0,
+        const int hd = cfg->attention_heads[i];
+        UV_REQUIRE(hd > 0 && c % 8 == 0 && c % cfg->norm_num_groups == 0 && c % hd == 0 && (c / hd) % 8 == 0,
                    "unet_create: block_out_channels[%d]=%d must be divisible by 8, groups and heads (head_dim multiple of 8)", i, c);
     }
     UV_REQUIRE(cfg->cross_attention_dim % 8 == 0, "unet_create: cross_attention_dim must be a multiple of 8");

@@ -483,8 +483,8 @@ struct Fwd {
     }
 
     // attention.py:104-153 + :280-346 (+ pnp_utils.py:20-100 when pnp_layer)
-    int transformer(const std::string& p, const Act& x, bool pnp_layer, Act* out) {
-        const int C = x.C, heads = u.cfg.attention_heads, d = C / heads, N = x.H * x.W;
+    int transformer(const std::string& p, const Act& x, bool pnp_layer, int heads, Act* out) {
+        const int C = x.C, d = C / heads, N = x.H * x.W;
         const long rows = x.rows();
         const std::string b = p + ".transformer_blocks.0";
         half_t* t0 = alloc(rows * C);
@@ -492,7 +492,7 @@ struct Fwd {
         RUN(groupnorm(x, nullptr, N, 1e-6f, p + ".norm", 0, t0));
         half_t* h = alloc(rows * C);
         if (!h) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, p + ".proj_in.weight#nhwc", p + ".proj_in.bias", C, h, C));
+        RUN(linear(t0, C, rows, C, p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight"), p + ".proj_in.bias", C, h, C));
         // ---- attn1
         half_t *gm, *bt;
         gm = W(b + ".norm1.weight"); bt = W(b + ".norm1.bias");
@@ -565,7 +565,8 @@ struct Fwd {
         out->imgs = x.imgs; out->H = x.H; out->W = x.W; out->C = C;
         out->p = alloc(rows * C);
         if (!out->p) return UV_ERR_STATE;
-        RUN(linear(h4, C, rows, C, p + ".proj_out.weight#nhwc", p + ".proj_out.bias", C, out->p, C, x.p, C));
+        RUN(linear(h4, C, rows, C, p + (u.find(p + ".proj_out.weight#nhwc") ? ".proj_out.weight#nhwc" : ".proj_out.weight"), p + ".proj_out.bias", C, out->p,
+                   C, x.p, C));
         free(h4);
         return UV_OK;
     }
@@ -637,7 +638,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
             x = y;
             if (has_attn) {
                 Act z;
-                RUN(f.transformer(p + ".attentions." + std::to_string(j), x, false, &z));
+                RUN(f.transformer(p + ".attentions." + std::to_string(j), x, false, cfg.attention_heads[i], &z));
                 f.free(x.p);
                 x = z;
             }
@@ -654,7 +655,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     {
         Act y, z, w;
         RUN(f.resblock("mid_block.resnets.0", x, nullptr, boc[3], &y));
-        RUN(f.transformer("mid_block.attentions.0", y, false, &z));
+        RUN(f.transformer("mid_block.attentions.0", y, false, cfg.attention_heads[3], &z));
         f.free(y.p);
         RUN(f.resblock("mid_block.resnets.1", z, nullptr, boc[3], &w));
         f.free(z.p);
@@ -676,7 +677,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
             x = y;
             if (has_attn) {
                 Act z;
-                RUN(f.transformer(p + ".attentions." + std::to_string(j), x, j < 3 && pnp_layers[i][j], &z));
+                RUN(f.transformer(p + ".attentions." + std::to_string(j), x, j < 3 && pnp_layers[i][j], cfg.attention_heads[3 - i], &z));
                 f.free(x.p);
                 x = z;
             }
