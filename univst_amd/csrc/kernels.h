@@ -24,6 +24,7 @@ struct GemmParams {
     long ldr = 0;
     const half_t* bias2 = nullptr;     // second bias added after fp16 rounding (attn_temporal bias)
     int geglu = 0;                     // W rows interleaved [16 x | 16 gate]; writes N/2 columns x*gelu(gate)
+    int epi_lds = 0;                   // 256x320 kernel: transpose the tile through LDS for row-contiguous stores
 };
 
 struct AttnParams {
