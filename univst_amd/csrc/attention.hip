@@ -39,13 +39,12 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     constexpr int DV = DV16 * 16;
     constexpr int VSTR = lds_stride_bytes(DV * 2) / 2;
     constexpr int KS = DPAD / 32;
-    constexpr int KCH = DPAD / 8, VCH = DV / 8;
-    constexpr int NKL = (KT * KCH + 255) / 256, NVL = (KT * VCH + 255) / 256;   // staging loads per thread
     constexpr int TILE = KT * KSTR + KT * VSTR;
     constexpr bool DBUF = (2 * TILE * 2) <= 48 * 1024;     // double-buffer when it keeps >= 3 blocks per CU
     // ONES: head_dim 40 leaves V columns 40..47 of the 48-wide V tile unused -> column 40 holds 1.0 so the PV MFMA
     // accumulates the softmax denominator (from the SAME fp16-rounded P that multiplies V) in a spare O^T row.
     constexpr bool ONES = (DV16 == 3);
+    constexpr int D = ONES ? 40 : DV16 * 16;                 // the head dim this instantiation serves (checked by the dispatcher)
     __shared__ __attribute__((aligned(16))) half_t smem[(DBUF ? 2 : 1) * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,7 +54,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     const int qblk = lid % nqb;
     const int h = (lid / nqb) % p.heads;
     const int bf = lid / (nqb * p.heads);
-    const int d = p.d;
+    constexpr int d = D;
 
     // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
     h8 qf[QB][KS];
@@ -83,83 +82,97 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     }
 
     const int ntile = (p.Nkv + KT - 1) / KT;
-    const int T = (p.src_cnt ? p.src_cnt[bf] : p.nsrc) * ntile;
-    h8 kr[NKL], vr[NVL];
-    // per-thread staging geometry is tile-invariant: element offsets inside a [64-key] tile and validity of the chunk
-    unsigned koff[NKL], voff[NVL];
-    int krow[NKL], vrow[NVL];
-    bool kval[NKL], vval[NVL], vone[NVL];
+    // Only the D real columns of a K / V row are staged per tile; the zero padding up to DPAD / DV (and, for ONES, the
+    // 1.0 column) is written to both LDS buffers once, before the loop.
+    // The prefetch loads are inline asm on purpose: hipcc's waitcnt insertion merges the "Q fragments pending" state of
+    // the loop pre-header into every iteration and emitted s_waitcnt vmcnt(0) in front of the first QK^T MFMA, i.e. it
+    // waited for the prefetch it had just issued (a full L2/HBM latency exposed per key tile).  With asm loads the
+    // compiler tracks nothing; the single explicit vmcnt(0) sits in store_tile(), after the tile's MFMA + softmax work.
+    constexpr int DCH = D / 8;                                // 16-byte chunks per row actually loaded
+    constexpr int NL = (KT * DCH + 255) / 256;                // staging loads per thread, each for K and for V
+    constexpr int REM = KT * DCH - (NL - 1) * 256;            // threads active in the last round (whole waves)
+    static_assert(REM % 64 == 0, "staging rounds must be wave-uniform");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    h8 kr[NL], vr[NL];
+    unsigned gcol[NL], ksoff[NL], vsoff[NL];
+    int srow[NL];
 #pragma unroll
-    for (int i = 0; i < NKL; ++i) {
+    for (int i = 0; i < NL; ++i) {
         const int idx = tid + i * 256;
-        const int row = idx / KCH, ch = idx - row * KCH;
-        krow[i] = row;
-        kval[i] = (idx < KT * KCH) && (ch * 8 < d);
-        koff[i] = (unsigned)(row * (int)p.ldkv + h * d + ch * 8);
+        const int row = idx / DCH, ch = idx - row * DCH;
+        srow[i] = row;
+        gcol[i] = (unsigned)(h * D + ch * 8);
+        ksoff[i] = (unsigned)(row * KSTR + ch * 8);
+        vsoff[i] = (unsigned)(KT * KSTR + row * VSTR + ch * 8);
     }
+    auto gload16 = [](const half_t* ptr) {
+        h8 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr));
+        return v;
+    };
+    const int nsrc_eff = p.src_cnt ? p.src_cnt[bf] : p.nsrc;
+    const int T = nsrc_eff * ntile;
+    int nx_s = 0, nx_t = 0;               // (source, tile-in-source) of the NEXT tile to load
+    long nx_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc]) * p.Nkv * p.ldkv;      // element offset of that source's first key row
+    bool ld_tail = false;                 // the tile in the prefetch registers has rows past Nkv (zeroed at store time)
+    int ld_t0 = 0;
+    auto load_tile = [&]() {              // global -> registers; completes under the MFMAs of the current tile
+        const int t0 = nx_t * KT;
+        const half_t* kb = p.k + nx_off + (long)t0 * p.ldkv;
+        const half_t* vb = p.v + nx_off + (long)t0 * p.ldkv;
+        ld_tail = t0 + KT > p.Nkv;
+        ld_t0 = t0;
+        const int rmax = p.Nkv - 1 - t0;
 #pragma unroll
-    for (int i = 0; i < NVL; ++i) {
-        const int idx = tid + i * 256;
-        const int row = idx / VCH, ch = idx - row * VCH;
-        vrow[i] = row;
-        vval[i] = (idx < KT * VCH) && (ch * 8 < d);
-        vone[i] = ONES && (idx < KT * VCH) && (ch * 8 == d);
-        voff[i] = (unsigned)(row * (int)p.ldkv + h * d + ch * 8);
-    }
-    auto load_tile = [&](int tt) {        // global -> registers (flies under the MFMAs of the previous tile)
-        const int s = tt / ntile, t0 = (tt - s * ntile) * KT;
-        const long src = p.src_idx[bf * p.nsrc + s];
-        const half_t* kb = p.k + (src * p.Nkv + t0) * p.ldkv;
-        const half_t* vb = p.v + (src * p.Nkv + t0) * p.ldkv;
-        if (t0 + KT <= p.Nkv) {            // full tile (block-uniform): no per-row checks
-#pragma unroll
-            for (int i = 0; i < NKL; ++i) kr[i] = kval[i] ? *reinterpret_cast<const h8*>(kb + koff[i]) : zero8;
-#pragma unroll
-            for (int i = 0; i < NVL; ++i) {
-                h8 v = vval[i] ? *reinterpret_cast<const h8*>(vb + voff[i]) : zero8;
-                if (vone[i]) v[0] = (half_t)1.f;
-                vr[i] = v;
+        for (int i = 0; i < NL; ++i) {
+            if (i + 1 < NL || wave_u * 64 < REM) {
+                const int r = ld_tail ? (srow[i] < rmax ? srow[i] : rmax) : srow[i];      // clamp: never read past the source
+                const unsigned off = (unsigned)(r * (int)p.ldkv) + gcol[i];
+                kr[i] = gload16(kb + off);
+                vr[i] = gload16(vb + off);
             }
-        } else {
+        }
+        if (++nx_t == ntile) {            // source boundary (<= nsrc-1 times per block): fetch the next source frame index
+            nx_t = 0;
+            if (++nx_s < nsrc_eff) nx_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc + nx_s]) * p.Nkv * p.ldkv;
+        }
+    };
+    auto store_tile = [&](half_t* buf) {
+        asm volatile("s_waitcnt vmcnt(0)");
 #pragma unroll
-            for (int i = 0; i < NKL; ++i)
-                kr[i] = (kval[i] && t0 + krow[i] < p.Nkv) ? *reinterpret_cast<const h8*>(kb + koff[i]) : zero8;
-#pragma unroll
-            for (int i = 0; i < NVL; ++i) {
-                const bool rok = t0 + vrow[i] < p.Nkv;
-                h8 v = (vval[i] && rok) ? *reinterpret_cast<const h8*>(vb + voff[i]) : zero8;
-                if (vone[i] && rok) v[0] = (half_t)1.f;
-                vr[i] = v;
+        for (int i = 0; i < NL; ++i) {
+            if (i + 1 < NL || wave_u * 64 < REM) {
+                asm volatile("" : "+v"(kr[i]), "+v"(vr[i]));          // the registers are defined from here on
+                if (ld_tail && ld_t0 + srow[i] >= p.Nkv) { kr[i] = zero8; vr[i] = zero8; }
+                *reinterpret_cast<h8*>(&buf[ksoff[i]]) = kr[i];
+                *reinterpret_cast<h8*>(&buf[vsoff[i]]) = vr[i];
             }
         }
     };
-    auto store_tile = [&](half_t* Ks, half_t* Vs) {
-#pragma unroll
-        for (int i = 0; i < NKL; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / KCH, ch = idx - row * KCH;
-            if (idx < KT * KCH) *reinterpret_cast<h8*>(&Ks[row * KSTR + ch * 8]) = kr[i];
+    {   // one-time LDS image: zeros everywhere, 1.0 in V column D of every key row (ONES).  Rows past Nkv keep their 1.0:
+        // their probabilities are exp2(-inf) = 0.
+        constexpr int TOT = (DBUF ? 2 : 1) * TILE;
+        for (int i = tid * 8; i < TOT; i += 256 * 8) *reinterpret_cast<h8*>(&smem[i]) = zero8;
+        __syncthreads();
+        if (ONES && tid < KT) {
+            smem[KT * KSTR + tid * VSTR + D] = (half_t)1.f;
+            if (DBUF) smem[TILE + KT * KSTR + tid * VSTR + D] = (half_t)1.f;
         }
-#pragma unroll
-        for (int i = 0; i < NVL; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / VCH, ch = idx - row * VCH;
-            if (idx < KT * VCH) *reinterpret_cast<h8*>(&Vs[row * VSTR + ch * 8]) = vr[i];
-        }
-    };
+    }
 
     const float c = p.scale_log2e;
-    load_tile(0);
-    store_tile(smem, smem + KT * KSTR);
+    load_tile();
+    store_tile(smem);
     __syncthreads();
 
+    int cur_s = 0, cur_t = 0;             // (source, tile-in-source) of the tile being consumed
+    float lw = p.src_logw ? p.src_logw[bf * p.nsrc] : 0.f;            // log2 multiplicity of the current source ...
+    float lwr = lw * (1.f / c);                                       // ... in raw-score units
     for (int tt = 0; tt < T; ++tt) {
         half_t* Ks = smem + (DBUF ? (tt & 1) * TILE : 0);
         half_t* Vs = Ks + KT * KSTR;
-        if (tt + 1 < T) load_tile(tt + 1);
-        const int t0 = (tt % ntile) * KT;
-        const float lw = p.src_logw ? p.src_logw[bf * p.nsrc + tt / ntile] : 0.f;    // log2 multiplicity of this source
-        const float lwr = lw * (1.f / c);                                               // ... in raw-score units
+        if (tt + 1 < T) load_tile();
+        const int t0 = cur_t * KT;
 
         // ---- S^T = K Q^T
         f4 sc[4][QB];
@@ -198,18 +211,18 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
             mx = max3f(mx, sc[2][qb][3], sc[3][qb][0]);
             mx = max3f(mx, sc[3][qb][1], sc[3][qb][2]);
             mx = max3f(mx, sc[3][qb][3], sc[3][qb][3]);
-            {
+            // deferred rescale (guide T13): keep the old running max while the new one is at most 2^DEFER larger in
+            // the exp2 domain; P is then bounded by 2^DEFER (fp16 keeps full relative precision there) and the O^T
+            // rescale + its accumulator traffic is skipped for the whole wave.  mrun is uniform over the 4 lane groups of a
+            // query column, so "row max exceeds the bound" == "some lane's local max does": the cross-lane reduction (two
+            // LDS-crossbar permutes + waits) is only paid inside the rare branch.
+            mx += lwr;
+            float alpha = 1.f;
+            if (__builtin_amdgcn_ballot_w64((mx - mrun[qb]) * c > DEFER) != 0) {
                 const float o16 = __shfl_xor(mx, 16, 64);
                 mx = max3f(mx, o16, o16);
                 const float o32 = __shfl_xor(mx, 32, 64);
                 mx = max3f(mx, o32, o32);
-            }
-            // deferred rescale (guide T13): keep the old running max while the new one is at most 2^DEFER larger in
-            // the exp2 domain; P is then bounded by 2^DEFER (fp16 keeps full relative precision there) and the O^T
-            // rescale + its accumulator traffic is skipped for the whole wave.
-            mx += lwr;
-            float alpha = 1.f;
-            if (__builtin_amdgcn_ballot_w64((mx - mrun[qb]) * c > DEFER) != 0) {
                 const float mnew = fmaxf(mrun[qb], mx);
                 alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * c);
                 mrun[qb] = mnew;
@@ -264,8 +277,15 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
             }
         }
         if (!DBUF) __syncthreads();      // everyone finished reading the single buffer
-        if (tt + 1 < T) store_tile(smem + (DBUF ? ((tt + 1) & 1) * TILE : 0), smem + (DBUF ? ((tt + 1) & 1) * TILE : 0) + KT * KSTR);
+        if (tt + 1 < T) store_tile(smem + (DBUF ? ((tt + 1) & 1) * TILE : 0));
         __syncthreads();
+        if (++cur_t == ntile) {
+            cur_t = 0;
+            if (++cur_s < nsrc_eff && p.src_logw) {
+                lw = p.src_logw[bf * p.nsrc + cur_s];
+                lwr = lw * (1.f / c);
+            }
+        }
     }
 
     // ---- finalize: O^T[d = dv*16 + g*4 + r][q = l15] / l
