@@ -230,7 +230,7 @@ def debug_tr16():
     return out
 
 
-PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>", "gemm_kernel<*,1>", "attn_kernel_occ2<64,3,4>",
+PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>", "gemm_kernel<*,1>", "attn_pp40_kernel<true>",
                    "attn_kernel_occ3<96,5,2>", "attn_kernel<other>", "groupnorm", "layernorm", "adain_shift")
 
 

@@ -328,6 +328,402 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
     attn_body<DPAD, DV16, QB>(p);
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// head_dim 40, long sequences (the 64x64-level self-attention: 5 launches per UNet call, a third of the step):
+// a software-pipelined variant of attn_body<64, 3, 4>.
+//
+// Per key the softmax costs more VALU issue time (exp2, cvt, max) than the two MFMAs cost matrix time, and in the plain
+// body a wave runs them back to back: QK^T, then softmax, then PV.  Here a wave works in 32-key steps with TWO score
+// register sets: while the VALU exponentiates step s, the matrix pipe computes the scores of step s+1; while the matrix
+// pipe runs PV of step s, the VALU takes the running max of step s+1 (guide T15, with the interleave pinned by
+// sched_group_barrier so the in-order wave really alternates MFMA and VALU issue).  K/V tiles of 64 keys live in a 3-stage
+// LDS ring (48 KB, two blocks per CU), prefetched two tiles ahead through registers; one barrier per tile.
+//
+// FOLD: the scale and the running max move INTO the QK^T MFMA.  Q is pre-multiplied by scale*log2(e) (one fp16 rounding
+// per element, 2^-11 relative), and the 24 padding columns of the 64-wide contraction carry, on the K side, three columns
+// of 1.0 and, on the Q side, (-M_hi, -M_lo, +log2 multiplicity): the MFMA then returns s*c - M + lw directly and the
+// per-score fma disappears (8 of ~29 VALU issue slots per query block and step).  M is the running reference quantised to
+// 1/64 and split in a multiple of 8 plus a remainder so both parts are exact in fp16; softmax is shift invariant, so a
+// quantised reference is not an approximation.  On a (rare) reference change the pending scores are shifted by the same
+// delta and O^T is rescaled after the pending PV, the order T13 requires.
+template <bool FOLD>
+__global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
+    constexpr int D = 40, DV16 = 3, QB = 4, NST = 3;
+    constexpr int KSTR = lds_stride_bytes(64 * 2) / 2;       // 80 halfs
+    constexpr int VSTR = lds_stride_bytes(48 * 2) / 2;       // 48 halfs
+    constexpr int TILE = KT * KSTR + KT * VSTR;              // 16 KB per stage
+    __shared__ __attribute__((aligned(16))) half_t smem[NST * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % nqb;
+    const int h = (lid / nqb) % p.heads;
+    const int bf = lid / (nqb * p.heads);
+    const float c = p.scale_log2e;
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int ntile = (p.Nkv + KT - 1) / KT;
+    const int nsrc_eff = p.src_cnt ? p.src_cnt[bf] : p.nsrc;
+    const int T = nsrc_eff * ntile;
+    float lw_cur = p.src_logw ? p.src_logw[bf * p.nsrc] : 0.f;
+
+    // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
+    h8 qf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int dc = ks * 32 + g * 8;
+            h8 v = (qrow < p.Nq && dc < D) ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + dc) : zero8;
+            if (FOLD) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * c);
+            }
+            qf[qb][ks] = v;
+        }
+        if (FOLD && g == 1) qf[qb][1][2] = (half_t)lw_cur;        // column 42: + log2 multiplicity of the source
+    }
+    auto set_shift = [&](int qb, float M) {                       // columns 40 / 41 of Q' <- -M (FOLD)
+        const float hi = floorf(M * 0.125f) * 8.f, lo = M - hi;
+        if (g == 1) {
+            qf[qb][1][0] = (half_t)(-hi);
+            qf[qb][1][1] = (half_t)(-lo);
+        }
+    };
+
+    f4 o[DV16][QB];
+    float mrun[QB], mc[QB];        // FOLD: mrun = quantised reference M (log2 units).  else: raw running max, mc = lw - mrun*c
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = FOLD ? 0.f : -INFINITY;
+        mc[qb] = 0.f;
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) o[dv][qb] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- staging (see attn_body): 5 chunks of 16 B per K / V row, asm loads, explicit wait at store time
+    constexpr int DCH = D / 8, NL = 2, REM = KT * DCH - 256;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    h8 kr[NL], vr[NL];
+    unsigned gcol[NL], ksoff[NL], vsoff[NL];
+    int srow[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / DCH, ch = idx - row * DCH;
+        srow[i] = row;
+        gcol[i] = (unsigned)(h * D + ch * 8);
+        ksoff[i] = (unsigned)(row * KSTR + ch * 8);
+        vsoff[i] = (unsigned)(KT * KSTR + row * VSTR + ch * 8);
+    }
+    auto gload16 = [](const half_t* ptr) {
+        h8 v;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr));
+        return v;
+    };
+    int ld_s = 0, ld_t = 0;
+    long ld_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc]) * p.Nkv * p.ldkv;
+    bool ld_tail = false;
+    int ld_t0 = 0;
+    auto load_tile = [&]() {
+        const int t0 = ld_t * KT;
+        const half_t* kb = p.k + ld_off + (long)t0 * p.ldkv;
+        const half_t* vb = p.v + ld_off + (long)t0 * p.ldkv;
+        ld_tail = t0 + KT > p.Nkv;
+        ld_t0 = t0;
+        const int rmax = p.Nkv - 1 - t0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            if (i + 1 < NL || wave_u * 64 < REM) {
+                const int r = ld_tail ? (srow[i] < rmax ? srow[i] : rmax) : srow[i];
+                const unsigned off = (unsigned)(r * (int)p.ldkv) + gcol[i];
+                kr[i] = gload16(kb + off);
+                vr[i] = gload16(vb + off);
+            }
+        }
+        if (++ld_t == ntile) {
+            ld_t = 0;
+            if (++ld_s < nsrc_eff) ld_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc + ld_s]) * p.Nkv * p.ldkv;
+        }
+    };
+    auto store_tile = [&](half_t* buf) {
+        asm volatile("s_waitcnt vmcnt(0)");
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            if (i + 1 < NL || wave_u * 64 < REM) {
+                asm volatile("" : "+v"(kr[i]), "+v"(vr[i]));
+                if (ld_tail && ld_t0 + srow[i] >= p.Nkv) { kr[i] = zero8; vr[i] = zero8; }
+                *reinterpret_cast<h8*>(&buf[ksoff[i]]) = kr[i];
+                *reinterpret_cast<h8*>(&buf[vsoff[i]]) = vr[i];
+            }
+        }
+    };
+    {   // one-time LDS image: zeros, 1.0 in V column 40 (softmax denominator), FOLD: 1.0 in K columns 40..42
+        for (int i = tid * 8; i < NST * TILE; i += 256 * 8) *reinterpret_cast<h8*>(&smem[i]) = zero8;
+        __syncthreads();
+        if (tid < KT) {
+#pragma unroll
+            for (int st = 0; st < NST; ++st) {
+                smem[st * TILE + KT * KSTR + tid * VSTR + D] = (half_t)1.f;
+                if (FOLD) {
+                    smem[st * TILE + tid * KSTR + D] = (half_t)1.f;
+                    smem[st * TILE + tid * KSTR + D + 1] = (half_t)1.f;
+                    smem[st * TILE + tid * KSTR + D + 2] = (half_t)1.f;
+                }
+            }
+        }
+    }
+
+    // ---- the four pipeline pieces
+    const int kf_off = l15 * KSTR + g * 8;
+    const int vf_off = KT * KSTR + (g * 4 + (l15 >> 2)) * VSTR + (l15 & 3) * 4;
+    auto kfrag_read = [&](const half_t* st, int hh, h8 (&kf)[2][2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (hh * 32 + kb * 16) * KSTR + ks * 32]);
+    };
+    auto vfrag_read = [&](const half_t* st, int hh, h8 (&vf)[DV16]) {
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) {
+            const half_t* vp = &st[vf_off + hh * 32 * VSTR + dv * 16];
+            fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
+            fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * VSTR));
+            h8 a;
+            a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
+            a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
+            vf[dv] = a;
+        }
+    };
+    auto qk = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {        // S^T of one 32-key step: 16 MFMAs
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], z, 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], sc[kb][qb], 0, 0, 0);
+    };
+    auto exp_part = [&](const f4 (&sc)[2][QB], h8 (&pb)[QB]) {    // P^T (fp16, B operand of the PV MFMA)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            union { fh2 h[4]; h8 v; } u;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                float e0, e1, e2, e3;
+                if (FOLD) {
+                    e0 = __builtin_amdgcn_exp2f(sc[kb][qb][0]); e1 = __builtin_amdgcn_exp2f(sc[kb][qb][1]);
+                    e2 = __builtin_amdgcn_exp2f(sc[kb][qb][2]); e3 = __builtin_amdgcn_exp2f(sc[kb][qb][3]);
+                } else {
+                    e0 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][0], c, mc[qb])); e1 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][1], c, mc[qb]));
+                    e2 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][2], c, mc[qb])); e3 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][3], c, mc[qb]));
+                }
+                u.h[kb * 2] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+                u.h[kb * 2 + 1] = __builtin_amdgcn_cvt_pkrtz(e2, e3);
+            }
+            pb[qb] = u.v;
+        }
+    };
+    auto pv = [&](const h8 (&vf)[DV16], const h8 (&pb)[QB]) {      // O^T += V^T P^T: 12 MFMAs
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o[dv][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dv], pb[qb], o[dv][qb], 0, 0, 0);
+    };
+    auto local_max = [&](const f4 (&sc)[2][QB], float (&mx)[QB]) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float m = max3f(sc[0][qb][0], sc[0][qb][1], sc[0][qb][2]);
+            m = max3f(m, sc[0][qb][3], sc[1][qb][0]);
+            m = max3f(m, sc[1][qb][1], sc[1][qb][2]);
+            mx[qb] = max3f(m, sc[1][qb][3], sc[1][qb][3]);
+        }
+    };
+    auto mask_tail = [&](f4 (&sc)[2][QB], int key0) {              // keys >= Nkv of a tail tile -> -inf
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key0 + kb * 16 + g * 4 + r >= p.Nkv) sc[kb][qb][r] = -INFINITY;
+    };
+    // reference update for the scores `sc` of the NEXT step (deferred, T13).  Everything exponentiated so far is already in
+    // O^T (the PV of the previous step precedes this in program order), so O^T is rescaled exactly once per change.
+    auto decide = [&](f4 (&sc)[2][QB], const float (&mx)[QB], float lw, bool first) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (FOLD) {
+                if (__builtin_amdgcn_ballot_w64(first || mx[qb] > DEFER) != 0) {
+                    float m = mx[qb];
+                    const float o16 = __shfl_xor(m, 16, 64);
+                    m = max3f(m, o16, o16);
+                    const float o32 = __shfl_xor(m, 32, 64);
+                    m = max3f(m, o32, o32);
+                    float delta = floorf(m * 64.f + 0.5f) * (1.f / 64.f);          // shifted row max, quantised
+                    if (!first) delta = fmaxf(delta, 0.f);
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    mrun[qb] += delta;
+                    set_shift(qb, mrun[qb]);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        sc[kb][qb][0] -= delta; sc[kb][qb][1] -= delta; sc[kb][qb][2] -= delta; sc[kb][qb][3] -= delta;
+                    }
+#pragma unroll
+                    for (int dv = 0; dv < DV16; ++dv) {
+                        o[dv][qb][0] *= alpha; o[dv][qb][1] *= alpha; o[dv][qb][2] *= alpha; o[dv][qb][3] *= alpha;
+                    }
+                }
+            } else {
+                const float lwr = lw * (1.f / c);
+                float m = mx[qb] + lwr;
+                if (__builtin_amdgcn_ballot_w64((m - mrun[qb]) * c > DEFER) != 0) {
+                    const float o16 = __shfl_xor(m, 16, 64);
+                    m = max3f(m, o16, o16);
+                    const float o32 = __shfl_xor(m, 32, 64);
+                    m = max3f(m, o32, o32);
+                    const float mnew = fmaxf(mrun[qb], m);
+                    const float alpha = __builtin_amdgcn_exp2f((mrun[qb] - mnew) * c);
+                    mrun[qb] = mnew;
+#pragma unroll
+                    for (int dv = 0; dv < DV16; ++dv) {
+                        o[dv][qb][0] *= alpha; o[dv][qb][1] *= alpha; o[dv][qb][2] *= alpha; o[dv][qb][3] *= alpha;
+                    }
+                }
+                mc[qb] = fmaf(-mrun[qb], c, lw);
+            }
+        }
+    };
+    auto set_lw = [&](float lw) {                                  // FOLD: column 42 of Q' <- log2 multiplicity of the source
+        if (g == 1) {
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) qf[qb][1][2] = (half_t)lw;
+        }
+    };
+// pin the issue order inside the two overlapped regions (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8, DS read 0x100, TRANS 0x400)
+#define UV_PP_PHASE1()                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        if (i_ < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+        if (!FOLD) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);             \
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        \
+    }
+#define UV_PP_PHASE2()                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                        \
+    }
+
+// an empty asm that "uses" four values: keeps their producers in this basic block (LLVM otherwise sinks the exp2 / max
+// work below the next branch, out of reach of the interleave above)
+#define UV_PP_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+
+    // ---- prologue: tiles 0 and 1 into the ring, scores + reference of step (0, 0)
+    load_tile();
+    store_tile(smem);
+    if (T > 1) {
+        load_tile();
+        store_tile(smem + TILE);
+    }
+    __syncthreads();
+
+    f4 scA[2][QB], scB[2][QB];
+    h8 kf[2][2], vf[DV16], pb[QB];
+    float mx[QB];
+    int nx_s = 0, nx_t = (ntile > 1) ? 1 : 0;            // (source, tile-in-source) of tile tt+1
+    if (ntile == 1) nx_s = 1;
+    float lw_nxt = (nx_s != 0 && nx_s < nsrc_eff && p.src_logw) ? p.src_logw[bf * p.nsrc + nx_s] : lw_cur;
+    int t0_cur = 0, t0_nxt = nx_t * KT;
+    half_t* b_cur = smem;
+    half_t* b_nxt = smem + TILE;
+    half_t* b_ld = smem + 2 * TILE;
+
+    kfrag_read(b_cur, 0, kf);
+    qk(kf, scA);
+    if (t0_cur + KT > p.Nkv) mask_tail(scA, t0_cur);
+    local_max(scA, mx);
+    decide(scA, mx, lw_cur, true);
+    kfrag_read(b_cur, 1, kf);
+
+    for (int tt = 0; tt < T; ++tt) {
+        const bool has_next = tt + 1 < T;
+        if (tt + 2 < T) load_tile();                     // tile tt+2 -> registers, two tiles ahead
+        // ---- step (tt, 0): scores of (tt, 1) on the matrix pipe while (tt, 0) is exponentiated
+        vfrag_read(b_cur, 0, vf);
+        qk(kf, scB);
+        exp_part(scA, pb);
+        UV_PP_PIN4(pb);
+        UV_PP_PHASE1();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t0_cur + KT > p.Nkv) mask_tail(scB, t0_cur + 32);
+        kfrag_read(b_nxt, 0, kf);
+        pv(vf, pb);
+        local_max(scB, mx);
+        UV_PP_PIN4(mx);
+        UV_PP_PHASE2();
+        __builtin_amdgcn_sched_barrier(0);
+        decide(scB, mx, lw_cur, false);
+        // ---- step (tt, 1): scores of (tt+1, 0)
+        if (FOLD && lw_nxt != lw_cur) set_lw(lw_nxt);
+        vfrag_read(b_cur, 1, vf);
+        qk(kf, scA);
+        exp_part(scB, pb);
+        UV_PP_PIN4(pb);
+        UV_PP_PHASE1();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next && t0_nxt + KT > p.Nkv) mask_tail(scA, t0_nxt);
+        kfrag_read(b_nxt, 1, kf);
+        pv(vf, pb);
+        local_max(scA, mx);
+        UV_PP_PIN4(mx);
+        UV_PP_PHASE2();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) decide(scA, mx, lw_nxt, false);
+        // ---- end of tile: tile tt+2 into the stage tile tt-1 vacated one barrier ago
+        if (tt + 2 < T) store_tile(b_ld);
+        __syncthreads();
+        half_t* tb = b_cur; b_cur = b_nxt; b_nxt = b_ld; b_ld = tb;
+        t0_cur = t0_nxt;
+        lw_cur = lw_nxt;
+        if (++nx_t == ntile) {
+            nx_t = 0;
+            if (++nx_s < nsrc_eff && p.src_logw) lw_nxt = p.src_logw[bf * p.nsrc + nx_s];
+        }
+        t0_nxt = nx_t * KT;
+    }
+#undef UV_PP_PHASE1
+#undef UV_PP_PIN4
+#undef UV_PP_PHASE2
+
+    // ---- finalize: O^T[d = dv*16 + g*4 + r][q = l15] / l, l = O^T row 40 (the ones column of V)
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const float l = __shfl(o[DV16 - 1][qb][0], 32 + l15, 64);
+        const float inv = 1.f / l;
+        const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
+        if (qrow >= p.Nq) continue;
+        half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) {
+            const int dc = dv * 16 + g * 4;
+            if (dc < D) {
+                h4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                *reinterpret_cast<h4*>(op + dc) = ov;
+            }
+        }
+    }
+}
+
 // lane l of a 64-lane wave reports what ds_read_b64_tr_b16 returned for a known LDS image (bring-up aid).
 __global__ void tr16_probe_kernel(float* out) {
     __shared__ __attribute__((aligned(16))) half_t sm[64 * 16];
@@ -347,6 +743,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_occ2(AttnParams p) {
 template <int DPAD, int DV16>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
     static const int qb4 = getenv("UNIVST_ATTN_QB4") ? atoi(getenv("UNIVST_ATTN_QB4")) : 1;   // 64 query rows per wave for long sequences
+    if constexpr (DPAD == 64 && DV16 == 3) {
+        // UNIVST_ATTN_PP (A/B aid): 2 = software-pipelined kernel with scale/max folded into the MFMA (default),
+        // 1 = software-pipelined, plain softmax arithmetic, 0 = attn_body
+        static const int pp = getenv("UNIVST_ATTN_PP") ? atoi(getenv("UNIVST_ATTN_PP")) : 2;
+        if (pp && p.Nq >= 2048) {
+            const int nqb4 = (p.Nq + 255) / 256;
+            if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((attn_pp40_kernel<false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
     if constexpr (DPAD <= 64) {
         if (qb4 && p.Nq >= 2048) {
             const int nqb4 = (p.Nq + 255) / 256;

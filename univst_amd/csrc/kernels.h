@@ -92,7 +92,7 @@ enum {
     UV_CLS_CONV_BIG = 1,    // gemm_big_kernel<1>
     UV_CLS_GEMM = 2,        // gemm_kernel<*,0,...>
     UV_CLS_CONV = 3,        // gemm_kernel<*,1,...>
-    UV_CLS_ATTN_D40 = 4,    // attn_kernel_occ2<64,3,4> (long sequences) / attn_kernel_occ3<64,3,2>
+    UV_CLS_ATTN_D40 = 4,    // attn_pp40_kernel<true> (long sequences) / attn_kernel_occ3<64,3,2>
     UV_CLS_ATTN_D80 = 5,    // attn_kernel*<96,5,*>
     UV_CLS_ATTN_OTHER = 6,  // remaining attention instantiations
     UV_CLS_GROUPNORM = 7,
