@@ -545,151 +545,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 }
 
 
-// ----------------------------------------------------------------------------------------------------------------
-// Same 256 x 320 output tile, deeper pipeline: 32-wide k tiles in a 4-stage LDS ring (4 x 36 KB), THREE tiles of
-// LDS-DMA in flight per CU at all times (counted s_waitcnt vmcnt, raw s_barrier — guide T3/T4), instead of one tile
-// issued and drained per barrier.  The big tile was DMA-latency bound (one 72 KB tile per ~2.5 us = 29 GB/s per CU);
-// keeping ~108 KB in flight raises that without more LDS.  64-byte LDS rows use the chunk permutation
-// pc = lc ^ f[(row>>2)&3], f = [0,3,2,1] (brute-forced conflict-free for the ds_read_b128 lane groups).
-// Waves 0-3 issue 5 DMA pieces per k tile, waves 4-7 issue 4 (36 pieces of 16 rows), hence the two wait ladders.
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams p) {
-    constexpr int NF = 10, BMB = 256, BNB = 320, BK = 32, LDSH = 32, NBUF = 4;
-    constexpr int TILE = (BMB + BNB) * LDSH;                 // halfs per stage (36 KB)
-    __shared__ __attribute__((aligned(16))) half_t smem[NBUF * TILE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wn = wave & 1, wm = wave >> 1;
-    const int l15 = lane & 15, g = lane >> 4;
-    const int nt_n = p.N / BNB;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = lid % nt_n, tm = lid / nt_n;
-    const int m0 = tm * BMB, n0 = tn * BNB;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    // ---- staging geometry: DMA piece q = wave + 8*i covers tile rows [16q, 16q+16) (rows 0..255 = X, 256..575 = W)
-    const int rsub = lane >> 2;
-    const int lc = (lane & 3) ^ ((0x1230 >> (((lane >> 4) & 3) * 4)) & 3);       // logical 16-byte chunk of this lane
-    unsigned xoff[2], woff[3];
-    int x_iy0[2], x_ix0[2], x_img[2];
-    bool x_ok[2], w_ok[3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (wave + 8 * i) * 16 + rsub;
-        x_ok[i] = m < p.M;
-        if (MODE == 0) {
-            xoff[i] = (unsigned)((long)m * p.ldx + lc * 8);
-        } else {
-            const int hw = p.Ho * p.Wo;
-            const int img = m / hw, rem = m - img * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int pad = (p.taps == 9) ? 1 : 0;
-            x_iy0[i] = oy * p.stride - pad;
-            x_ix0[i] = ox * p.stride - pad;
-            x_img[i] = img * p.Hs;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int n = n0 + (wave + 8 * i) * 16 + rsub;       // (pieces 16.. are W rows: q - 16 = wave + 8*i)
-        w_ok[i] = n < p.N && (wave + 8 * i) < 20;
-        woff[i] = (unsigned)((long)n * p.K + lc * 8);
-    }
-    const int Cin = p.C1 + p.C2;
-    int tap = 0, cc = lc * 8, khalf = 0;                      // conv k state of the NEXT tile to issue
-    if (MODE == 1 && !p.korder) {
-        while (cc >= Cin) { cc -= Cin; ++tap; }
-    }
-    const half_t* zp = uv_zero_page;
-    auto glds16 = [&](const half_t* src, half_t* dst) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-    auto issue_tile = [&](int kt) {               // tiles MUST be issued in k order (conv k state advances)
-        const int k0 = kt * BK;
-        half_t* base = smem + (kt & (NBUF - 1)) * TILE + wave_u * 16 * LDSH;
-        const bool kok = (k0 + lc * 8) < p.K;
-        if (MODE == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) glds16((x_ok[i] && kok) ? p.X + xoff[i] + k0 : zp, base + 128 * i * LDSH);
-        } else {
-            const int ky = (p.taps == 9) ? tap / 3 : 0;
-            const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
-            const int He = p.Hs << p.up, We = p.Ws << p.up;
-            const int c = p.korder ? cc + khalf * 32 : cc;
-            const bool src2 = c >= p.C1;
-            const half_t* sb = src2 ? p.X2 : p.X;
-            const int cs = src2 ? p.C2 : p.C1;
-            const int co = src2 ? c - p.C1 : c;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-                const bool ok = x_ok[i] && kok && iy >= 0 && iy < He && ix >= 0 && ix < We;
-                const long pix = (long)(x_img[i] + (iy >> p.up)) * p.Ws + (ix >> p.up);
-                glds16(ok ? sb + pix * cs + co : zp, base + 128 * i * LDSH);
-            }
-            if (p.korder) {                       // tap-inner: two 32-wide halves of a 64-channel slab per tap
-                khalf ^= 1;
-                if (khalf == 0 && ++tap == 9) { tap = 0; cc += 64; }
-            } else {
-                cc += BK;
-                while (cc >= Cin) { cc -= Cin; ++tap; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16((w_ok[i] && kok) ? p.W + woff[i] + k0 : zp, base + (256 + 128 * i) * LDSH);
-        if (wave_u < 4) glds16((w_ok[2] && kok) ? p.W + woff[2] + k0 : zp, base + (256 + 256) * LDSH);
-    };
-    auto wait_tile = [&](int n_after) {           // wait until all but the newest n_after tiles of THIS wave have landed
-        if (wave_u < 4) {
-            if (n_after >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (n_after == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            if (n_after >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (n_after == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    };
-
-    f4 acc[NF][4];
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    issue_tile(0);
-    if (nk > 1) issue_tile(1);
-    if (nk > 2) issue_tile(2);
-    const int ch = (g ^ ((0x1230 >> (((l15 >> 2) & 3) * 4)) & 3)) * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int after = nk - 1 - kt;
-        wait_tile(after > 2 ? 2 : after);
-        __builtin_amdgcn_s_barrier();             // tile kt landed for every wave; everyone is done reading stage (kt-1)&3
-        if (kt + 3 < nk) issue_tile(kt + 3);      // -> stage (kt+3)&3 == (kt-1)&3
-        const half_t* Xs = smem + (kt & (NBUF - 1)) * TILE;
-        const half_t* Ws = Xs + BMB * LDSH;
-        h8 a[NF];
-#pragma unroll
-        for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * 160 + i * 16 + l15) * LDSH + ch]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            h8 b = *reinterpret_cast<const h8*>(&Xs[(wm * 64 + j * 16 + l15) * LDSH + ch]);
-#pragma unroll
-            for (int i = 0; i < NF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][j], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f4 col[NF];
-#pragma unroll
-        for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
-        gemm_epilogue_row<NF>(p, col, m0 + wm * 64 + j * 16 + l15, n0 + wn * 160, g);
-    }
-}
-
 // y[m][n] = sum_k act(x[m][k]) W[n][k] + b[n], M <= 8: one wave per output column (time embeddings).
 __global__ __launch_bounds__(256) void linear_small_kernel(const half_t* __restrict__ x, const half_t* __restrict__ W,
                                                            const half_t* __restrict__ b, half_t* __restrict__ y,
@@ -765,11 +620,9 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             GemmParams q = p;
             q.epi_lds = epi && (!p.geglu || epi == 2) && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && al16(p.bias2) && al16(p.rowbias) &&
                         (!p.R || (p.ldr % 8 == 0 && al16(p.R)));
-            static const int pipe = getenv("UNIVST_GEMM_PIPE") ? atoi(getenv("UNIVST_GEMM_PIPE")) : 0;
-            if (pipe && p.K % 32 == 0) {
-                if (mode == 0) hipLaunchKernelGGL((gemm_pipe_kernel<0>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
-                else hipLaunchKernelGGL((gemm_pipe_kernel<1>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
-            } else if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
+            // (A 32-wide-k, 4-stage DMA ring with counted vmcnt, and the same with two wave groups staggered by half a
+            // k tile + s_setprio, were both measured on this tile: -10 % and -0..18 %)
+            if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
             else hipLaunchKernelGGL((gemm_big_kernel<1>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
             uv_prof_end(stream);
             UV_LAUNCH_CHECK();
