@@ -111,10 +111,12 @@ int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta
  * Optional (may be NULL): src_cnt int32 [BF] = number of leading sources actually used for that frame, src_logw fp32
  * [BF][nsrc] = log2 multiplicity of a source — a frame that occurs m times in the reference's concatenated key set
  * ([prev, cur, first] at f = 0, 1) is read ONCE with log2(m) added to its scores, which is the same softmax.
+ * q_prescaled != 0: q already carries the factor log2(e)/sqrt(head_dim) (the UNet graph folds it into the to_q weights
+ * for head_dim 40, so the fastest kernel can take scale and running max inside the QK^T MFMA); 0: plain q.
  * Replaces attention.py:384-420, pnp_utils.py:59-92 and diffusers AttnProcessor2_0. */
 int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
                      const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv,
-                     int heads, int head_dim, void* stream);
+                     int heads, int head_dim, int q_prescaled, void* stream);
 /* AdaIN-guided attention shift in place on the fused QKV buffer [3*F*N, 3C]; stats_ws: 4*F*2C floats.
  * Replaces pnp_utils.py:47-57 + attention_adain :114-125. */
 int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, float alpha, float beta, float gamma,

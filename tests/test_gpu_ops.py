@@ -191,24 +191,38 @@ def sdpa_ref(q, k, v, heads):
     return unet_ref.sdpa(q.float(), k.float(), v.float(), heads)
 
 
-@pytest.mark.parametrize("heads,d,N,Fr,mode", [(2, 40, 2048 + 40, 2, "stock"), (8, 40, 2304, 1, "pnp"), (2, 16, 64, 3, "stock"), (2, 32, 256, 4, "pnp"), (8, 40, 576, 2, "stock"),
-                                                (8, 80, 128, 3, "pnp"), (8, 160, 64, 2, "stock"), (4, 64, 200, 2, "stock")])
-def test_attention_sparse_causal(nat, heads, d, N, Fr, mode):
-    """fused-QKV layout, K/V gathered by pointer from {prev, (cur), first} frames of the same branch."""
+def prescaled(q, d):
+    """(q', q'/c): q multiplied by c = log2(e)/sqrt(d) and rounded to fp16 once — what the UNet graph's folded to_q weights
+    produce — and the fp32 tensor the oracle must see so that both sides start from the SAME rounded values."""
+    c = 1.4426950408889634 / math.sqrt(d)
+    qp = (q.float() * c).to(torch.float16)
+    return qp, qp.float() / c
+
+
+@pytest.mark.parametrize("heads,d,N,Fr,mode,pre", [(2, 40, 2048 + 40, 2, "stock", 1), (8, 40, 2304, 1, "pnp", 1), (2, 40, 2048 + 40, 2, "stock", 0),
+                                                    (2, 16, 64, 3, "stock", 0), (2, 32, 256, 4, "pnp", 0), (8, 40, 576, 2, "stock", 0), (8, 40, 576, 2, "stock", 1),
+                                                    (8, 80, 128, 3, "pnp", 0), (8, 160, 64, 2, "stock", 0), (4, 64, 200, 2, "stock", 0)])
+def test_attention_sparse_causal(nat, heads, d, N, Fr, mode, pre):
+    """fused-QKV layout, K/V gathered by pointer from {prev, (cur), first} frames of the same branch.  pre: q carries
+    log2(e)/sqrt(d) already (head_dim 40, Nq >= 2048 then runs the software-pipelined kernel)."""
     B, C = 3, heads * d
     qkv = rnd(B * Fr, N, 3 * C, seed=1)
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    qref = q
+    if pre:
+        qp, qref = prescaled(q, d)
+        qkv[..., :C] = qp
     index = [-1, 0, "first"] if mode == "stock" else [-1, "first"]
     kk = unet_ref.sparse_causal_gather(k.float().contiguous().cpu(), Fr, index).cuda()
     vv = unet_ref.sparse_causal_gather(v.float().contiguous().cpu(), Fr, index).cuda()
-    ref = sdpa_ref(q.contiguous(), kk, vv, heads)
+    ref = sdpa_ref(qref.contiguous(), kk, vv, heads)
     rows = []
     for b in range(B):
         for f in range(Fr):
             prev, first = b * Fr + max(f - 1, 0), b * Fr
             rows.append([prev, b * Fr + f, first] if mode == "stock" else [prev, first])
     src = torch.tensor(rows, dtype=torch.int32).cuda()
-    got = nat.attention(q, k, v, src, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C)
+    got = nat.attention(q, k, v, src, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, q_prescaled=bool(pre))
     close(got, ref, rtol=4e-3)
 
 
@@ -249,6 +263,47 @@ def test_attention_softmax_spike(nat):
     k[0, 70] = q[0, 9] * 5
     src = torch.zeros(1, 1, dtype=torch.int32).cuda()
     close(nat.attention(q, k, v, src, heads), sdpa_ref(q, k, v, heads), rtol=4e-3)
+
+
+# ---- the software-pipelined head_dim-40 kernel (Nq >= 2048): scale / running reference folded into the QK^T MFMA ----------
+def test_attention_d40_long_reference_jumps(nat):
+    """large, late, positive AND negative score excursions: the quantised (multiple-of-8 + remainder) reference is rewritten
+    mid-stream, pending scores are shifted, O^T rescaled once; ragged key count (tail tile) on top."""
+    heads, d, N = 2, 40, 2048 + 72
+    C = heads * d
+    q, k, v = rnd(1, N, C, seed=1) * 2, rnd(1, N, C, seed=2), rnd(1, N, C, seed=3)
+    k[0, 1500] = q[0, 5] * 6            # raw score ~ 6*|q|^2: hundreds of log2 units above the rest, in a late tile
+    k[0, 70] = q[0, 9] * 5
+    k[0, 2100] = q[0, 2000] * 4         # inside the tail tile
+    q[0, 300] = -k[0, :64].mean(0) * 30  # a query whose early scores are all strongly negative (negative first reference)
+    src = torch.zeros(1, 1, dtype=torch.int32).cuda()
+    qp, qref = prescaled(q, d)
+    close(nat.attention(qp, k, v, src, heads, q_prescaled=True), sdpa_ref(qref, k, v, heads), rtol=4e-3)
+    close(nat.attention(q, k, v, src, heads), sdpa_ref(q, k, v, heads), rtol=4e-3)      # plain q: attn_body
+
+
+def test_attention_d40_long_merged_sources_and_text(nat):
+    heads, d, N = 8, 40, 2048
+    C = heads * d
+    qkv = rnd(3, N, 3 * C, seed=1)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    qp, qref = prescaled(q, d)
+    qkv[..., :C] = qp
+    dup = torch.tensor([[0, 0, 0], [0, 1, 0], [1, 2, 0]], dtype=torch.int32).cuda()
+    kk = torch.stack([torch.cat([k[j] for j in row]) for row in dup.tolist()]).float()
+    vv = torch.stack([torch.cat([v[j] for j in row]) for row in dup.tolist()]).float()
+    ref = sdpa_ref(qref.contiguous(), kk, vv, heads)
+    cnt = torch.tensor([1, 2, 3], dtype=torch.int32).cuda()
+    lw = torch.tensor([[math.log2(3), 0, 0], [1.0, 0, 0], [0, 0, 0]], dtype=torch.float32).cuda()
+    got = nat.attention(q, k, v, dup, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, src_cnt=cnt, src_logw=lw, q_prescaled=True)
+    close(got, ref, rtol=4e-3)
+    # 77 text tokens against 2304 queries: two key tiles, the second with 13 valid rows
+    qx = rnd(2, 2304, C, seed=4)
+    kv = rnd(2, 77, 2 * C, seed=5)
+    kt, vt = kv[..., :C], kv[..., C:]
+    src = torch.tensor([[0], [1]], dtype=torch.int32).cuda()
+    qxp, qxref = prescaled(qx, d)
+    close(nat.attention(qxp, kt, vt, src, heads, ldkv=2 * C, Nkv=77, C_=C, q_prescaled=True), sdpa_ref(qxref, kt, vt, heads), rtol=4e-3)
 
 
 @pytest.mark.parametrize("C,N,Fr,idx", [(64, 64, 4, 0), (320, 256, 3, 13), (1280, 64, 2, 25)])

@@ -46,7 +46,7 @@ SIGNATURES = {
     "univst_groupnorm_workspace_bytes": (_L, [_L, _I, _I]),
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
-    "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "univst_attention_adain_shift": (_I, [_P, _L, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_latent_adain": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "univst_latent_adain_stats": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -172,14 +172,15 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return out
 
 
-def attention(q, k, v, src_idx, heads, ldq=None, ldkv=None, Nq=None, Nkv=None, C_=None, src_cnt=None, src_logw=None):
-    """q [BF,Nq,C], k/v [S,Nkv,C] (S source blocks), src_idx int32 [BF,nsrc] -> [BF,Nq,C]."""
+def attention(q, k, v, src_idx, heads, ldq=None, ldkv=None, Nq=None, Nkv=None, C_=None, src_cnt=None, src_logw=None, q_prescaled=False):
+    """q [BF,Nq,C], k/v [S,Nkv,C] (S source blocks), src_idx int32 [BF,nsrc] -> [BF,Nq,C].
+    q_prescaled: q already multiplied by log2(e)/sqrt(head_dim)."""
     BF, Nq_, Cq = q.shape
     C_ = C_ or Cq
     out = torch.empty(BF, Nq_, C_, device=q.device, dtype=torch.float16)
     check(load().univst_attention(ptr(q), ldq or q.stride(1), ptr(k), ptr(v), ldkv or k.stride(1), ptr(out), C_,
                                   ptr(src_idx), ptr(src_cnt), ptr(src_logw), src_idx.shape[1], BF, Nq_, Nkv or k.shape[1], heads, C_ // heads,
-                                  stream_ptr()), "attention")
+                                  int(bool(q_prescaled)), stream_ptr()), "attention")
     return out
 
 

@@ -160,7 +160,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
         }
     }
 
-    const float c = p.scale_log2e;
+    const float c = p.q_prescaled ? 1.f : p.scale_log2e;
     load_tile();
     store_tile(smem);
     __syncthreads();
@@ -339,8 +339,10 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // sched_group_barrier so the in-order wave really alternates MFMA and VALU issue).  K/V tiles of 64 keys live in a 3-stage
 // LDS ring (48 KB, two blocks per CU), prefetched two tiles ahead through registers; one barrier per tile.
 //
-// FOLD: the scale and the running max move INTO the QK^T MFMA.  Q is pre-multiplied by scale*log2(e) (one fp16 rounding
-// per element, 2^-11 relative), and the 24 padding columns of the 64-wide contraction carry, on the K side, three columns
+// FOLD: the scale and the running max move INTO the QK^T MFMA.  Q arrives pre-multiplied by scale*log2(e) — the UNet graph
+// folds that factor into the to_q weights (AttnParams::q_prescaled), so Q is rounded to fp16 once, exactly as often as the
+// reference rounds it; multiplying an already rounded Q here would add a second 2^-11 error that shows on keys of very
+// large norm (tests) — and the 24 padding columns of the 64-wide contraction carry, on the K side, three columns
 // of 1.0 and, on the Q side, (-M_hi, -M_lo, +log2 multiplicity): the MFMA then returns s*c - M + lw directly and the
 // per-score fma disappears (8 of ~29 VALU issue slots per query block and step).  M is the running reference quantised to
 // 1/64 and split in a multiple of 8 plus a remainder so both parts are exact in fp16; softmax is shift invariant, so a
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     const int qblk = lid % nqb;
     const int h = (lid / nqb) % p.heads;
     const int bf = lid / (nqb * p.heads);
-    const float c = p.scale_log2e;
+    const float c = p.q_prescaled ? 1.f : p.scale_log2e;     // FOLD is only dispatched for prescaled q (c == 1)
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     const int ntile = (p.Nkv + KT - 1) / KT;
@@ -378,10 +380,6 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         for (int ks = 0; ks < 2; ++ks) {
             const int dc = ks * 32 + g * 8;
             h8 v = (qrow < p.Nq && dc < D) ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + dc) : zero8;
-            if (FOLD) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (half_t)((float)v[e] * c);
-            }
             qf[qb][ks] = v;
         }
         if (FOLD && g == 1) qf[qb][1][2] = (half_t)lw_cur;        // column 42: + log2 multiplicity of the source
@@ -744,10 +742,10 @@ template <int DPAD, int DV16>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
     static const int qb4 = getenv("UNIVST_ATTN_QB4") ? atoi(getenv("UNIVST_ATTN_QB4")) : 1;   // 64 query rows per wave for long sequences
     if constexpr (DPAD == 64 && DV16 == 3) {
-        // UNIVST_ATTN_PP (A/B aid): 2 = software-pipelined kernel with scale/max folded into the MFMA (default),
-        // 1 = software-pipelined, plain softmax arithmetic, 0 = attn_body
+        // UNIVST_ATTN_PP (A/B aid): 2 = software-pipelined kernel with scale/max folded into the MFMA when q is prescaled
+        // (default; plain q takes attn_body), 1 = software-pipelined with plain softmax arithmetic, 0 = attn_body
         static const int pp = getenv("UNIVST_ATTN_PP") ? atoi(getenv("UNIVST_ATTN_PP")) : 2;
-        if (pp && p.Nq >= 2048) {
+        if (p.Nq >= 2048 && ((pp == 2 && p.q_prescaled) || pp == 1)) {
             const int nqb4 = (p.Nq + 255) / 256;
             if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_pp40_kernel<false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);

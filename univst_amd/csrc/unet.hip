@@ -58,6 +58,12 @@ __global__ void geglu_interleave_kernel(const half_t* __restrict__ in, half_t* _
     int src = j < 16 ? 16 * q + j : rows / 2 + 16 * q + (j - 16);
     out[i] = in[(long)src * cols + c];
 }
+// out[i] = fp16(in[i] * f): to_q weights with log2(e)/sqrt(head_dim) folded in (attention.hip, FOLD kernel)
+__global__ void scale_f16_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, long n, float f) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (half_t)((float)in[i] * f);
+}
+
 __global__ void count_not_dirac_kernel(const half_t* __restrict__ w, int Co, int Ci, int k, unsigned* cnt) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)Co * Ci * k) return;
@@ -196,6 +202,12 @@ int UNet::finalize(hipStream_t s) {
         size_t n = strlen(suf);
         return a.size() >= n && a.compare(a.size() - n, n, suf) == 0;
     };
+    auto level_of = [](const std::string& a) {      // resolution level (0 = finest) of a state-dict key
+        int i = 0;
+        if (sscanf(a.c_str(), "down_blocks.%d.", &i) == 1) return i;
+        if (sscanf(a.c_str(), "up_blocks.%d.", &i) == 1) return 3 - i;
+        return 3;                                    // mid_block
+    };
     for (const std::string& k : keys) {
         const WTensor& t = weights[k];
         if (k.find("conv_temporal.weight") != std::string::npos) {
@@ -234,6 +246,24 @@ int UNet::finalize(hipStream_t s) {
             UV_HIP(hipMemcpyAsync(d, t.ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
             UV_HIP(hipMemcpyAsync(d + C * K, tk->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
             UV_HIP(hipMemcpyAsync(d + 2 * C * K, tv->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            const int hd = (int)C / cfg.attention_heads[level_of(k)];
+            if (hd == 40) {                     // second copy whose Q rows carry log2(e)/sqrt(d) (AttnParams::q_prescaled)
+                half_t* d2;
+                rc = derive_alloc(p + "qkv#fused#qs", {3 * C, K}, &d2);
+                if (rc) return rc;
+                hipLaunchKernelGGL(scale_f16_kernel, dim3(nb(C * K)), dim3(256), 0, s, t.ptr, d2, C * K, 1.4426950408889634f / sqrtf((float)hd));
+                UV_HIP(hipMemcpyAsync(d2 + C * K, tk->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+                UV_HIP(hipMemcpyAsync(d2 + 2 * C * K, tv->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            }
+        } else if (ends(k, ".attn2.to_q.weight")) {
+            const long C = t.shape[0], K = t.shape[1];
+            const int hd = (int)C / cfg.attention_heads[level_of(k)];
+            if (hd == 40) {
+                half_t* d2;
+                int rc = derive_alloc(k + "#qs", {C, K}, &d2);
+                if (rc) return rc;
+                hipLaunchKernelGGL(scale_f16_kernel, dim3(nb(C * K)), dim3(256), 0, s, t.ptr, d2, C * K, 1.4426950408889634f / sqrtf((float)hd));
+            }
         } else if (ends(k, ".attn2.to_k.weight")) {
             std::string p = k.substr(0, k.size() - strlen("to_k.weight"));
             const WTensor* tv = find(p + "to_v.weight");
@@ -501,7 +531,8 @@ struct Fwd {
         const long extra_rows = u.world > 1 ? (long)2 * B * N : 0;     // received prev-frame + first-frame K/V (frame shard)
         half_t* qkv = alloc((rows + extra_rows) * 3 * C);
         if (!qkv) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".attn1.qkv#fused", "", 3 * C, qkv, 3 * C));
+        const bool qs = u.find(b + ".attn1.qkv#fused#qs") != nullptr;      // head_dim 40: scale folded into to_q (finalize)
+        RUN(linear(t0, C, rows, C, b + (qs ? ".attn1.qkv#fused#qs" : ".attn1.qkv#fused"), "", 3 * C, qkv, 3 * C));
         const bool registered = pnp_layer && pnp && pnp->registered;
         if (registered && pnp->idx >= pnp->eta1 && pnp->idx <= pnp->eta2 * 50.f) {
             UV_REQUIRE(B == 3, "PnP attention shift needs the three-branch batch (B=3), got B=%d", B);
@@ -519,6 +550,7 @@ struct Fwd {
         ap.nsrc = registered ? 2 : 3;
         ap.BF = x.imgs; ap.Nq = N; ap.Nkv = N; ap.heads = heads; ap.d = d;
         ap.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+        ap.q_prescaled = qs;
         RUN(uv_launch_attention(ap, s));
         free(qkv);
         half_t* h2 = alloc(rows * C);
@@ -532,13 +564,15 @@ struct Fwd {
         half_t* q2 = alloc(rows * C);
         half_t* kv = alloc((long)B * text_len * 2 * C);
         if (!q2 || !kv) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".attn2.to_q.weight", "", C, q2, C));
+        const bool qs2 = u.find(b + ".attn2.to_q.weight#qs") != nullptr;
+        RUN(linear(t0, C, rows, C, b + (qs2 ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight"), "", C, q2, C));
         RUN(linear(text, u.cfg.cross_attention_dim, (long)B * text_len, u.cfg.cross_attention_dim, b + ".attn2.kv#fused", "",
                    2 * C, kv, 2 * C));
         ap.q = q2; ap.ldq = C;
         ap.k = kv; ap.v = kv + C; ap.ldkv = 2 * C;
         ap.o = t0; ap.ldo = C;
         ap.src_idx = idx_text; ap.src_cnt = nullptr; ap.src_logw = nullptr; ap.nsrc = 1; ap.Nkv = text_len;
+        ap.q_prescaled = qs2;
         RUN(uv_launch_attention(ap, s));
         free(q2);
         free(kv);
