@@ -215,9 +215,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int l15 = lane & 15, g = lane >> 4;
 
     const int nt_n = (p.N + BN - 1) / BN;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = nt_n * ((p.M + BM - 1) / BM);
+    const int split = lid / ntiles;                     // split-K: blocks of one k range are adjacent (they share W's k range)
+    lid -= split * ntiles;
     const int tn = lid % nt_n, tm = lid / nt_n;
     const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = p.splits > 1 ? split * p.ktps : 0;
+    const int kt1 = p.splits > 1 ? (kt0 + p.ktps < nk_all ? kt0 + p.ktps : nk_all) : nk_all;
 
     // ---- per-thread staging geometry: chunk kc (8 halfs) of rows rb + 32*i
     const int rb = tid / CPR;
@@ -251,8 +257,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
     const int Cin = p.C1 + p.C2;
     int tap = 0, cc = kc * 8;          // MODE 1: (tap, channel) of this thread's chunk in the current k tile
-    if (MODE == 1 && !p.korder) {
-        while (cc >= Cin) { cc -= Cin; ++tap; }
+    if (MODE == 1) {
+        if (p.korder) {
+            tap = kt0 % 9;
+            cc += (kt0 / 9) * 64;
+        } else {
+            cc += kt0 * BK;
+            tap = cc / Cin;
+            cc -= tap * Cin;
+        }
     }
 
     h8 xr[XL], wr[WL];
@@ -343,12 +356,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk = kt1 - kt0;            // k tiles of THIS block (all of them unless split-K)
     if (GLDS) {
-        issue_tile(0, 0);
+        issue_tile(kt0 * BK, 0);
         advance_k();
     } else {
-        load_tile(0);
+        load_tile(kt0 * BK);
         advance_k();
         store_tile(0);
         __syncthreads();
@@ -360,11 +373,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         if (GLDS) {
             __syncthreads();              // (vmcnt(0) + barrier) tile kt landed for every wave; buffer (kt+1)&1 is free
             if (kt + 1 < nk) {            // next tile's DMA flies under this tile's MFMAs
-                issue_tile((kt + 1) * BK, (kt + 1) & 1);
+                issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1);
                 advance_k();
             }
         } else if (kt + 1 < nk) {                 // next tile's global loads fly under this tile's MFMAs
-            load_tile((kt + 1) * BK);
+            load_tile((kt0 + kt + 1) * BK);
             advance_k();
         }
 #pragma unroll
@@ -396,6 +409,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
 
     // ---- epilogue: lane holds rows n = nb + g*4 + r (r<4) of column m = mb + l15
+    if (p.splits > 1) {                   // split-K: raw fp32 partial sums, the epilogue runs in splitk_reduce_kernel
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wm * 16 * MF + j * 16 + l15;
+            if (m >= p.M) continue;
+            float* row = p.partial + ((long)split * p.M + m) * p.N;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                const int n = n0 + wn * NF * 16 + i * 16 + g * 4;
+                if (n + 3 < p.N) *reinterpret_cast<f4*>(row + n) = acc[i][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < MF; ++j) {
         f4 col[NF];
@@ -403,6 +430,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
         gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MF + j * 16 + l15, n0 + wn * NF * 16, g);
     }
+}
+
+// split-K second pass: sum the fp32 partials in split order (deterministic) and run the normal epilogue on 4 channels.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N / 4;
+    if (i >= (long)p.M * n4) return;
+    const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+    f4 a = *reinterpret_cast<const f4*>(p.partial + (long)m * p.N + n);
+    for (int sidx = 1; sidx < p.splits; ++sidx) a += *reinterpret_cast<const f4*>(p.partial + ((long)sidx * p.M + m) * p.N + n);
+    f4 col[1] = {a};
+    gemm_epilogue_row<1>(p, col, m, n, 0);
 }
 
 
@@ -636,28 +675,55 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     const bool small_m = variant0 == 5 && !nf5 && nt < 2 * uv_num_cus() && p.M > 64;
     if (small_m) nt = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
-    dim3 grid(nt), block(256);
+    // split-K when the tiles alone leave most CUs idle and K is long (deep levels; every level of a frame shard)
+    GemmParams q = p;
+    q.splits = 1;
+    bool own_ws = false;
+    static const int splitk = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
+    if (splitk && variant0 == 5 && !p.geglu && p.N % 4 == 0 && nt < 384) {
+        const int nk = (p.K + 63) / 64;
+        int s = (512 + nt - 1) / nt;
+        if (s > nk / 4) s = nk / 4;
+        if (s > 16) s = 16;
+        if (s >= 2) {
+            q.ktps = (nk + s - 1) / s;
+            q.splits = (nk + q.ktps - 1) / q.ktps;
+            const size_t need = (size_t)q.splits * p.M * p.N * sizeof(float);
+            if (q.partial && q.partial_bytes >= need) {
+            } else if (need <= UV_SPLITK_WS_BYTES) {   // stand-alone operator call: stream-ordered scratch
+                UV_HIP(hipMallocAsync((void**)&q.partial, need, stream));
+                own_ws = true;
+            } else {
+                q.splits = 1;
+            }
+        }
+    }
+    dim3 grid(nt * q.splits), block(256);
     static const int variant = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
                   2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
 #define UV_GEMM_LAUNCH(BK_, DB_, GL_)                                                                       \
     do {                                                                                                   \
         if (mode == 0) {                                                                                   \
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, BK_, DB_, GL_>), grid, block, 0, stream, p);    \
-            else hipLaunchKernelGGL((gemm_kernel<4, 0, BK_, DB_, GL_>), grid, block, 0, stream, p);        \
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, BK_, DB_, GL_>), grid, block, 0, stream, q);    \
+            else hipLaunchKernelGGL((gemm_kernel<4, 0, BK_, DB_, GL_>), grid, block, 0, stream, q);        \
         } else {                                                                                           \
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, BK_, DB_, GL_>), grid, block, 0, stream, p);    \
-            else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_, GL_>), grid, block, 0, stream, p);        \
+            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, BK_, DB_, GL_>), grid, block, 0, stream, q);    \
+            else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_, GL_>), grid, block, 0, stream, q);        \
         }                                                                                                  \
     } while (0)
     // UNIVST_GEMM_VARIANT (A/B aid): 5 = global_load_lds staging (default); 0 = register-staged, one LDS buffer;
     // 1 = register-staged, two LDS buffers.  The DMA path won every shape except none (tools/bench_gemm.py).
     if (variant == 5 && small_m) {
-        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, true, 2>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, true, 2>), grid, block, 0, stream, p);
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, true, 2>), grid, block, 0, stream, q);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, true, 2>), grid, block, 0, stream, q);
     } else if (variant == 5) UV_GEMM_LAUNCH(64, false, true);
     else if (variant == 1) UV_GEMM_LAUNCH(64, true, false);
     else UV_GEMM_LAUNCH(64, false, false);
+    if (q.splits > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, q);
+        if (own_ws) UV_HIP(hipFreeAsync(q.partial, stream));
+    }
     uv_prof_end(stream);
     UV_LAUNCH_CHECK();
     return UV_OK;

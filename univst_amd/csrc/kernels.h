@@ -25,6 +25,11 @@ struct GemmParams {
     const half_t* bias2 = nullptr;     // second bias added after fp16 rounding (attn_temporal bias)
     int geglu = 0;                     // W rows interleaved [16 x | 16 gate]; writes N/2 columns x*gelu(gate)
     int epi_lds = 0;                   // 256x320 kernel: transpose the tile through LDS for row-contiguous stores
+    // split-K (small M*N, long K: the deep UNet levels, and every level of a frame shard): grid = tiles x splits, each block
+    // reduces ktps k tiles into fp32 partials [splits][M][N]; a second kernel sums them in split order and applies the epilogue.
+    float* partial = nullptr;          // caller-provided workspace (UNet arena) or null (the launcher then uses hipMallocAsync)
+    size_t partial_bytes = 0;
+    int splits = 1, ktps = 0;          // set by the launcher
 };
 
 struct AttnParams {
@@ -43,6 +48,7 @@ struct AttnParams {
 };
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
+constexpr size_t UV_SPLITK_WS_BYTES = 48u << 20;   // enough for 512 blocks of 128 x 160 fp32 partials
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);
 struct UvGnComm {      // cross-rank reduction hook of the 5-D GroupNorm (frame sharding)

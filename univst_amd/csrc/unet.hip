@@ -298,7 +298,7 @@ int UNet::finalize(hipStream_t s) {
 
 int UNet::reserve(int B, int F, int H, int Wd) {
     const long rows0 = (long)B * F * H * Wd;
-    size_t need = (size_t)rows0 * cfg.block_out_channels[0] * 2 * 28 + (64u << 20);
+    size_t need = (size_t)rows0 * cfg.block_out_channels[0] * 2 * 28 + (64u << 20) + UV_SPLITK_WS_BYTES;
     if (arena.size < need) {
         UV_HIP(hipDeviceSynchronize());
         if (arena.base) UV_HIP(hipFree(arena.base));
@@ -375,6 +375,7 @@ struct Fwd {
     const int *idx_stock = nullptr, *idx_pnp = nullptr, *idx_text = nullptr, *cnt_stock = nullptr, *cnt_pnp = nullptr;
     const float *lw_stock = nullptr, *lw_pnp = nullptr;
     float* gn_ws = nullptr;
+    float* sk_ws = nullptr;        // split-K fp32 partials (UV_SPLITK_WS_BYTES)
     float* ad_ws = nullptr;
 
     half_t* alloc(long elems) {
@@ -433,6 +434,8 @@ struct Fwd {
         g.Y = out->p;
         g.ldy = Cout;
         if (!g.W || !g.bias) return u.missing_error();
+        g.partial = sk_ws;
+        g.partial_bytes = UV_SPLITK_WS_BYTES;
         return uv_launch_gemm(g, 1, s);
     }
     int linear(const half_t* X, long ldx, long M, int K, const std::string& wkey, const std::string& bkey, int N, half_t* Y,
@@ -452,6 +455,8 @@ struct Fwd {
         g.bias2 = bias2;
         g.geglu = geglu;
         if (!g.W || (!bkey.empty() && !g.bias)) return u.missing_error();
+        g.partial = sk_ws;
+        g.partial_bytes = UV_SPLITK_WS_BYTES;
         return uv_launch_gemm(g, 0, s);
     }
 
@@ -633,7 +638,8 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     f.lw_pnp = (const float*)(tab + BF_ * 11);
     f.gn_ws = (float*)arena.alloc((size_t)uv_groupnorm_workspace_floats(B * F, cfg.norm_num_groups) * sizeof(float));
     f.ad_ws = (float*)arena.alloc((size_t)F * 2 * boc[3] * 2 * sizeof(float) + 1024);
-    UV_REQUIRE(f.gn_ws && f.ad_ws, "forward: arena too small");
+    f.sk_ws = (float*)arena.alloc(UV_SPLITK_WS_BYTES);
+    UV_REQUIRE(f.gn_ws && f.ad_ws && f.sk_ws, "forward: arena too small");
 
     // ---- time embedding (unet_3d_condition.py:359-365)
     half_t* tsin = f.alloc((long)B * C0);
