@@ -462,9 +462,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     const int wn = wave & 1, wm = wave >> 1;
     const int l15 = lane & 15, g = lane >> 4;
     const int nt_n = (p.N + BNB - 1) / BNB;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = nt_n * ((p.M + BMB - 1) / BMB);
+    const int split = lid / ntiles;                           // split-K (see gemm_kernel)
+    lid -= split * ntiles;
     const int tn = lid % nt_n, tm = lid / nt_n;
     const int m0 = tm * BMB, n0 = tn * BNB;
+    const int nk_all = (p.K + BK - 1) / BK;
+    const int kt0 = p.splits > 1 ? split * p.ktps : 0;
+    const int kt1 = p.splits > 1 ? (kt0 + p.ktps < nk_all ? kt0 + p.ktps : nk_all) : nk_all;
 
     const int rb = tid >> 3;                                  // 0..63
     const int kc = (tid & 7) ^ (rb & 7);                      // logical chunk staged by this lane
@@ -497,8 +503,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
     const int Cin = p.C1 + p.C2;
     int tap = 0, cc = kc * 8;
-    if (MODE == 1 && !p.korder) {
-        while (cc >= Cin) { cc -= Cin; ++tap; }
+    if (MODE == 1) {
+        if (p.korder) {
+            tap = kt0 % 9;
+            cc += (kt0 / 9) * 64;
+        } else {
+            cc += kt0 * BK;
+            tap = cc / Cin;
+            cc -= tap * Cin;
+        }
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const half_t* zp = uv_zero_page;
@@ -547,12 +560,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = (p.K + BK - 1) / BK;
-    issue_tile(0, 0);
+    const int nk = kt1 - kt0;
+    issue_tile(kt0 * BK, 0);
     const int sw = l15 & 7;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                  // vmcnt(0) + barrier: tile kt landed everywhere, buffer (kt+1)&1 is free
-        if (kt + 1 < nk) issue_tile((kt + 1) * BK, (kt + 1) & 1);
+        if (kt + 1 < nk) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1);
         const half_t* Xs = smem + (kt & 1) * TILE;
         const half_t* Ws = Xs + BMB * LDSH;
 #pragma unroll
@@ -568,6 +581,17 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 for (int i = 0; i < NF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][j], 0, 0, 0);
             }
         }
+    }
+    if (p.splits > 1) {                   // split-K: raw fp32 partials; splitk_reduce_kernel runs the epilogue
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + l15;
+            if (m >= p.M) continue;
+            float* row = p.partial + ((long)split * p.M + m) * p.N + n0 + wn * 160 + g * 4;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) *reinterpret_cast<f4*>(row + i * 16) = acc[i][j];
+        }
+        return;
     }
     if (p.epi_lds) {
         __syncthreads();                  // every wave is done with the operand tiles: smem becomes the transpose scratch
@@ -648,8 +672,18 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         const long nblk = (long)((p.M + 255) / 256) * (p.N / 320);
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
         static const long bigmin_env = getenv("UNIVST_GEMM_BIGMIN") ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 0;
-        const long bigmin = bigmin_env ? bigmin_env : (mode == 1 ? 150 : 512);   // measured cross-over (tools/bench_gemm.py)
-        if (!nobig && p.N % 320 == 0 && nblk >= bigmin && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
+        const long bigmin = bigmin_env ? bigmin_env : 150;   // measured cross-over (tools/bench_gemm_mid.py)
+        // few tiles but a long reduction (the 8x8-level convs; most convs of a frame shard): the big tile with split-K
+        int bsplits = 1;
+        static const int splitk_big = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
+        if (splitk_big && !nobig && !p.geglu && p.N % 320 == 0 && nblk < bigmin && nblk >= 8 && p.K >= 128 * 64) {   // fp32 partials cost ~35 us: long reductions only
+            const int nk = (p.K + 63) / 64;
+            int sp = (int)((256 + nblk - 1) / nblk);
+            if (sp > nk / 24) sp = nk / 24;
+            if (sp > 8) sp = 8;
+            if (sp >= 2 && nblk * sp >= 128 && (size_t)sp * p.M * p.N * sizeof(float) <= UV_SPLITK_WS_BYTES) bsplits = sp;
+        }
+        if (!nobig && p.N % 320 == 0 && (nblk >= bigmin || bsplits > 1) && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
             uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : UV_CLS_CONV_BIG, 2.0 * p.M * (double)p.N * p.K,
                           2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
             // row-contiguous epilogue through LDS needs 16-byte aligned rows everywhere it touches; it pays for the plain
@@ -661,8 +695,24 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                         (!p.R || (p.ldr % 8 == 0 && al16(p.R)));
             // (A 32-wide-k, 4-stage DMA ring with counted vmcnt, and the same with two wave groups staggered by half a
             // k tile + s_setprio, were both measured on this tile: -10 % and -0..18 %)
-            if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
-            else hipLaunchKernelGGL((gemm_big_kernel<1>), dim3((unsigned)nblk), dim3(512), 0, stream, q);
+            bool own_ws = false;
+            q.splits = 1;
+            if (bsplits > 1) {
+                const int nk = (p.K + 63) / 64;
+                q.ktps = (nk + bsplits - 1) / bsplits;
+                q.splits = (nk + q.ktps - 1) / q.ktps;
+                const size_t need = (size_t)q.splits * p.M * p.N * sizeof(float);
+                if (!(q.partial && q.partial_bytes >= need)) {
+                    UV_HIP(hipMallocAsync((void**)&q.partial, need, stream));
+                    own_ws = true;
+                }
+            }
+            if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)(nblk * q.splits)), dim3(512), 0, stream, q);
+            else hipLaunchKernelGGL((gemm_big_kernel<1>), dim3((unsigned)(nblk * q.splits)), dim3(512), 0, stream, q);
+            if (q.splits > 1) {
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, q);
+                if (own_ws) UV_HIP(hipFreeAsync(q.partial, stream));
+            }
             uv_prof_end(stream);
             UV_LAUNCH_CHECK();
             return UV_OK;
