@@ -764,8 +764,14 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     const int QB = p.Nq >= 512 ? 2 : 1;
     const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
     dim3 grid(nqb * p.heads * p.BF), block(256);
-    if (QB == 2 && DPAD <= 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2>), grid, block, 0, stream, p);
-    else if (QB == 2) hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2>), grid, block, 0, stream, p);
+    if constexpr (DPAD <= 96) {           // (not instantiated for wider heads: at 168 VGPRs they spill, and a spilled prefetch
+        if (QB == 2) {                    //  register is read before its asm load has landed — tests/test_asm_hazards.py)
+            hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2>), grid, block, 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    if (QB == 2) hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1>), grid, block, 0, stream, p);
     UV_LAUNCH_CHECK();
     return UV_OK;
