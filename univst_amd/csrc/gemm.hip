@@ -722,7 +722,11 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     int BN = nf5 ? 160 : 128;
     int nt = ((p.M + BM_DEFAULT - 1) / BM_DEFAULT) * ((p.N + BN - 1) / BN);
     // small-M problems (deepest UNet level: 3072 rows): 64-row tiles double the block count so the chip is filled
-    const bool small_m = variant0 == 5 && !nf5 && nt < 2 * uv_num_cus() && p.M > 64;
+    // UNIVST_GEMM_SMALLM (A/B aid): 0 = never, 1 = whenever the 128-row tiles are < 2 per CU, 2 (default) = only when split-K cannot
+    // supply the parallelism instead (short K)
+    static const int smallm_mode = getenv("UNIVST_GEMM_SMALLM") ? atoi(getenv("UNIVST_GEMM_SMALLM")) : 2;
+    const bool small_m = variant0 == 5 && !nf5 && nt < 2 * uv_num_cus() && p.M > 64 && smallm_mode != 0 &&
+                         (smallm_mode == 1 || p.geglu || (p.K + 63) / 64 < 16);
     if (small_m) nt = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
     // split-K when the tiles alone leave most CUs idle and K is long (deep levels; every level of a frame shard)
