@@ -693,8 +693,10 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             GemmParams q = p;
             q.epi_lds = epi && (!p.geglu || epi == 2) && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && al16(p.bias2) && al16(p.rowbias) &&
                         (!p.R || (p.ldr % 8 == 0 && al16(p.R)));
-            // (A 32-wide-k, 4-stage DMA ring with counted vmcnt, and the same with two wave groups staggered by half a
-            // k tile + s_setprio, were both measured on this tile: -10 % and -0..18 %)
+            // (Measured and rejected on this tile, DESIGN.md §4: a 32-wide-k 4-stage DMA ring with counted vmcnt (-10 %), the same
+            // with two wave groups staggered by half a k tile + s_setprio (-0..18 %), and a five-phase / two-barriers-per-phase
+            // schedule with in-place restaging two k tiles ahead (the guide's 8-phase template on this shape: -3 % linears,
+            // -20 % convs).)
             bool own_ws = false;
             q.splits = 1;
             if (bsplits > 1) {
@@ -722,11 +724,11 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     int BN = nf5 ? 160 : 128;
     int nt = ((p.M + BM_DEFAULT - 1) / BM_DEFAULT) * ((p.N + BN - 1) / BN);
     // small-M problems (deepest UNet level: 3072 rows): 64-row tiles double the block count so the chip is filled
-    // UNIVST_GEMM_SMALLM (A/B aid): 0 = never, 1 = whenever the 128-row tiles are < 2 per CU, 2 (default) = only when split-K cannot
-    // supply the parallelism instead (short K)
+    // UNIVST_GEMM_SMALLM (A/B aid): 0 = never, 1 = whenever the 128-row tiles are < 2 per CU, 2 (default) = convs only when
+    // split-K cannot supply the parallelism instead (short K); linears always (measured: tools/bench_gemm_mid.py)
     static const int smallm_mode = getenv("UNIVST_GEMM_SMALLM") ? atoi(getenv("UNIVST_GEMM_SMALLM")) : 2;
     const bool small_m = variant0 == 5 && !nf5 && nt < 2 * uv_num_cus() && p.M > 64 && smallm_mode != 0 &&
-                         (smallm_mode == 1 || p.geglu || (p.K + 63) / 64 < 16);
+                         (smallm_mode == 1 || mode == 0 || p.geglu || (p.K + 63) / 64 < 16);
     if (small_m) nt = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
     // split-K when the tiles alone leave most CUs idle and K is long (deep levels; every level of a frame shard)
