@@ -493,6 +493,25 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             x_img[i] = img * p.Hs;
         }
     }
+    // Fast im2col addressing for the common case (3x3, tap-inner k order, no fused upsample): the pixel offset of tap
+    // (ky, kx) is the row's own base plus a wave-uniform delta, and padding validity is a 9-bit mask per row computed
+    // once — 3 VALU per DMA instead of ~25 (the conv kernel issued 149 non-MFMA VALU per 80 MFMAs; tools/pmc_gemm.sh).
+    const bool fast_conv = MODE == 1 && p.korder && p.up == 0 && p.taps == 9;
+    int x_pix0[4];
+    unsigned x_mask[4];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x_pix0[i] = (x_img[i] + x_iy0[i]) * p.Ws + x_ix0[i];
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = x_iy0[i] + t / 3, ix = x_ix0[i] + t % 3;
+                if (x_ok[i] && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) mk |= 1u << t;
+            }
+            x_mask[i] = mk;
+        }
+    }
     unsigned woff[5];
     bool w_ok[5];
 #pragma unroll
@@ -526,6 +545,19 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16((x_ok[i] && kok) ? p.X + xoff[i] + k0 : zp, Xd + 64 * i * LDSH);
+        } else if (fast_conv) {
+            const int tap_u = __builtin_amdgcn_readfirstlane(tap);             // (tap, slab) are block-uniform in this k order
+            const int slab_u = __builtin_amdgcn_readfirstlane(cc - kc * 8);
+            const bool src2 = slab_u >= p.C1;
+            const half_t* base = src2 ? p.X2 : p.X;
+            const int cs = src2 ? p.C2 : p.C1;
+            const int ky = tap_u / 3, kx = tap_u - 3 * ky;
+            const long delta = (long)(ky * p.Ws + kx) * cs + (src2 ? slab_u - p.C1 : slab_u) + kc * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = kok && ((x_mask[i] >> tap_u) & 1u);
+                glds16(ok ? base + (long)x_pix0[i] * cs + delta : zp, Xd + 64 * i * LDSH);
+            }
         } else {
             const int ky = (p.taps == 9) ? tap / 3 : 0;
             const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
