@@ -538,11 +538,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    auto issue_tile = [&](int k0, int buf) {
+    auto issue_tile = [&](int k0, int buf, int parts = 3) {      // parts: 1 = activation rows, 2 = weight rows (+ k-state advance)
         half_t* Xd = smem + buf * TILE + wave_u * 8 * LDSH;
         half_t* Wd = Xd + BMB * LDSH;
         const bool kok = (k0 + kc * 8) < p.K;
-        if (MODE == 0) {
+        if (!(parts & 1)) {
+        } else if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) glds16((x_ok[i] && kok) ? p.X + xoff[i] + k0 : zp, Xd + 64 * i * LDSH);
         } else if (fast_conv) {
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 glds16(ok ? base + pix * cs + co : zp, Xd + 64 * i * LDSH);
             }
         }
+        if (!(parts & 2)) return;
 #pragma unroll
         for (int i = 0; i < 5; ++i) glds16((w_ok[i] && kok) ? p.W + woff[i] + k0 : zp, Wd + 64 * i * LDSH);
         if (MODE == 1) {
@@ -597,11 +599,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     const int sw = l15 & 7;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                  // vmcnt(0) + barrier: tile kt landed everywhere, buffer (kt+1)&1 is free
-        if (kt + 1 < nk) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1);
+        const bool more = kt + 1 < nk;
+        if (more) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1, p.issue_mode ? 1 : 3);
         const half_t* Xs = smem + (kt & 1) * TILE;
         const half_t* Ws = Xs + BMB * LDSH;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 1 && more && p.issue_mode) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1, 2);
             const int ch = ((ks * 4 + g) ^ sw) * 8;
             h8 a[NF];
 #pragma unroll
@@ -723,6 +727,10 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             static const int epi = getenv("UNIVST_GEMM_EPI") ? atoi(getenv("UNIVST_GEMM_EPI")) : 1;
             auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
             GemmParams q = p;
+            // next tile's DMA: activation rows before the first k-half's MFMAs, weight rows before the second (1, default; +2..8 % on
+            // the linears: the LDS-DMA writes at 64 B/clk and competes with the fragment reads) or all at once (0)
+            static const int issue_mode = getenv("UNIVST_GEMM_ISSUE") ? atoi(getenv("UNIVST_GEMM_ISSUE")) : 1;
+            q.issue_mode = issue_mode;
             q.epi_lds = epi && (!p.geglu || epi == 2) && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && al16(p.bias2) && al16(p.rowbias) &&
                         (!p.R || (p.ldr % 8 == 0 && al16(p.R)));
             // (Measured and rejected on this tile, DESIGN.md §4: a 32-wide-k 4-stage DMA ring with counted vmcnt (-10 %), the same

@@ -30,6 +30,7 @@ struct GemmParams {
     float* partial = nullptr;          // caller-provided workspace (UNet arena) or null (the launcher then uses hipMallocAsync)
     size_t partial_bytes = 0;
     int splits = 1, ktps = 0;          // set by the launcher
+    int issue_mode = 0;                // 256x320 kernel, A/B aid: how the next tile's DMA is spread over the current tile's MFMAs
 };
 
 struct AttnParams {
