@@ -107,6 +107,30 @@ def test_conv_big_tile_path(nat):
     close(nat.conv_nhwc(nhwc(x), conv_w(w), bias=b, upsample=True), nhwc(ref))
 
 
+def test_split_k_paths(nat):
+    """few output tiles, long reduction: fp32 partials [splits][M][N] + splitk_reduce_kernel (which runs the epilogue), on the
+    128-row tiles (any N) and on the 256x320 tile (K >= 8192, 8..149 tiles)."""
+    # small tiles: M tail, N not a multiple of the tile, bias + residual in the reduction kernel
+    M, N, K = 517, 96, 4096
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+    close(nat.linear(x, w, bias=b, residual=r), x.float() @ w.float().T + b.float() + r.float())
+    # 256x320 tile, linear: 9 x 4 tiles, K = 8192 -> 5 splits
+    M, N, K = 2048 + 5, 1280, 8192
+    x, w = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=1 / math.sqrt(K))
+    b, r = rnd(N, seed=7), rnd(M, N, seed=8)
+    close(nat.linear(x, w, bias=b, residual=r), x.float() @ w.float().T + b.float() + r.float())
+    # 256x320 tile, tap-inner conv over a virtual concat (K = 9 * 960), per-branch row bias + residual
+    imgs, C1, C2, Co, H = 32, 640, 320, 320, 16          # 32 tiles x 5 splits
+    x1, x2 = rnd(imgs, C1, H, H, seed=9), rnd(imgs, C2, H, H, seed=10)
+    wc = rnd(Co, C1 + C2, 3, 3, seed=11, scale=1 / math.sqrt(9 * (C1 + C2)))
+    bc, rb, res = rnd(Co, seed=12), rnd(16, Co, seed=13), rnd(imgs, Co, H, H, seed=14)
+    ref = F.conv2d(torch.cat([x1, x2], 1).float(), wc.float(), bc.float(), padding=1)
+    ref = ref + rb.float().repeat_interleave(2, 0)[:, :, None, None] + res.float()
+    got = nat.conv_nhwc_tapinner(nhwc(x1), conv_w_ti(wc), bias=bc, x2=nhwc(x2), rowbias=rb, rows_per_rowbias=2 * H * H, residual=nhwc(res))
+    close(got, nhwc(ref))
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
