@@ -75,7 +75,7 @@ def test_linear_geglu(nat):
 
 
 def test_linear_big_tile_path(nat):
-    """shapes that dispatch to the 256x320 GLDS kernel (>= 512 tiles), incl. M tail, K tail, bias+residual, GEGLU."""
+    """shapes that dispatch to the 256x320 GLDS kernel (>= 150 tiles), incl. M tail, K tail, bias+residual, GEGLU."""
     M = 131072 + 77
     for N, K in ((320, 320), (640, 72)):
         x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
