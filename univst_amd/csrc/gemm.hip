@@ -34,7 +34,7 @@ __device__ __attribute__((aligned(256))) half_t uv_zero_page[128];
 template <int NF>
 __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 (&col)[NF], int m, int nb, int g) {
     if (m >= p.M) return;
-    const half_t* rbias = p.rowbias ? p.rowbias + (long)(m / p.rows_per_rb) * p.N : nullptr;
+    const half_t* rbias = p.rowbias ? p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) : nullptr;
     if (p.geglu) {
         if constexpr (NF % 2 == 0) {
 #pragma unroll
@@ -138,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
                 }
                 if (p.rowbias) {
-                    const h8 bv = *reinterpret_cast<const h8*>(p.rowbias + (long)(m / p.rows_per_rb) * p.N + n);
+                    const h8 bv = *reinterpret_cast<const h8*>(p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) + n);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
                 }
@@ -731,7 +731,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             // the linears: the LDS-DMA writes at 64 B/clk and competes with the fragment reads) or all at once (0)
             static const int issue_mode = getenv("UNIVST_GEMM_ISSUE") ? atoi(getenv("UNIVST_GEMM_ISSUE")) : 1;
             q.issue_mode = issue_mode;
-            q.epi_lds = epi && (!p.geglu || epi == 2) && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && al16(p.bias2) && al16(p.rowbias) &&
+            q.epi_lds = epi && (!p.geglu || epi == 2) && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && al16(p.bias2) && al16(p.rowbias) && p.ldrb % 8 == 0 &&
                         (!p.R || (p.ldr % 8 == 0 && al16(p.R)));
             // (Measured and rejected on this tile, DESIGN.md §4: a 32-wide-k 4-stage DMA ring with counted vmcnt (-10 %), the same
             // with two wave groups staggered by half a k tile + s_setprio (-0..18 %), and a five-phase / two-barriers-per-phase

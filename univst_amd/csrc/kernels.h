@@ -20,6 +20,7 @@ struct GemmParams {
     const half_t* bias = nullptr;      // [N]
     const half_t* rowbias = nullptr;   // [M / rows_per_rb, N]  (time-embedding add per branch)
     int rows_per_rb = 1;
+    long ldrb = 0;                     // row stride of rowbias (0: N) — the UNet graph projects all 22 time embeddings in one launch
     const half_t* R = nullptr;         // residual [M, ldr]
     long ldr = 0;
     const half_t* bias2 = nullptr;     // second bias added after fp16 rounding (attn_temporal bias)

@@ -37,6 +37,8 @@ struct UNet {
     univst_unet_cfg cfg;
     std::unordered_map<std::string, WTensor> weights, derived;
     std::unordered_map<long, int*> idx_tables;
+    std::unordered_map<std::string, long> temb_off;    // resnet prefix -> column offset in the fused time_emb_proj (finalize)
+    long temb_total = 0;
     Arena arena;
     bool finalized = false;
     unsigned* d_counter = nullptr;

@@ -283,6 +283,34 @@ int UNet::finalize(hipStream_t s) {
             hipLaunchKernelGGL(geglu_interleave_kernel, dim3(nb((long)rows * cols)), dim3(256), 0, s, t.ptr, d, rows, cols);
         }
     }
+    {   // all resnets' time_emb_proj stacked into one [sum Cout, 4*C0] matrix: one projection launch per forward instead of 22
+        std::vector<std::string> tk;
+        for (const std::string& k : keys)
+            if (ends(k, ".time_emb_proj.weight")) tk.push_back(k);
+        std::sort(tk.begin(), tk.end());
+        temb_off.clear();
+        temb_total = 0;
+        for (const std::string& k : tk) {
+            temb_off[k.substr(0, k.size() - strlen(".time_emb_proj.weight"))] = temb_total;
+            temb_total += weights[k].shape[0];
+        }
+        if (!tk.empty()) {
+            const long K = weights[tk[0]].shape[1];
+            half_t *wa, *ba;
+            int rc = derive_alloc("time_emb_proj#all.weight", {temb_total, K}, &wa);
+            if (rc) return rc;
+            rc = derive_alloc("time_emb_proj#all.bias", {temb_total}, &ba);
+            if (rc) return rc;
+            for (const std::string& k : tk) {
+                const std::string pre = k.substr(0, k.size() - strlen(".time_emb_proj.weight"));
+                const WTensor& wt = weights[k];
+                const WTensor* bt = find(pre + ".time_emb_proj.bias");
+                UV_REQUIRE(bt && wt.shape[1] == K, "%s: time_emb_proj bias missing or width mismatch", pre.c_str());
+                UV_HIP(hipMemcpyAsync(wa + temb_off[pre] * K, wt.ptr, wt.shape[0] * K * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+                UV_HIP(hipMemcpyAsync(ba + temb_off[pre], bt->ptr, wt.shape[0] * sizeof(half_t), hipMemcpyDeviceToDevice, s));
+            }
+        }
+    }
     UV_LAUNCH_CHECK();
     unsigned bad = 0;
     UV_HIP(hipMemcpyAsync(&bad, d_counter, sizeof(unsigned), hipMemcpyDeviceToHost, s));
@@ -376,6 +404,7 @@ struct Fwd {
     const float *lw_stock = nullptr, *lw_pnp = nullptr;
     float* gn_ws = nullptr;
     float* sk_ws = nullptr;        // split-K fp32 partials (UV_SPLITK_WS_BYTES)
+    half_t* temb_all = nullptr;    // [B, temb_total]: every resnet's time_emb_proj(SiLU(emb)), one launch per forward
     float* ad_ws = nullptr;
 
     half_t* alloc(long elems) {
@@ -401,7 +430,7 @@ struct Fwd {
                                    eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s, sharded ? &gc : nullptr);
     }
     int conv(const Act& a, const Act* b, const std::string& p, int Cout, int taps, int stride, int up, const half_t* rowbias,
-             const half_t* R, Act* out) {
+             const half_t* R, Act* out, long ldrb = 0) {
         GemmParams g;
         g.X = a.p;
         g.X2 = b ? b->p : nullptr;
@@ -422,6 +451,7 @@ struct Fwd {
         g.W = W(p + (g.korder ? ".weight#ti" : ".weight#nhwc"));
         g.bias = W(p + ".bias");
         g.rowbias = rowbias;
+        g.ldrb = ldrb;
         g.rows_per_rb = F * g.Ho * g.Wo;
         g.R = R;
         g.ldr = Cout;
@@ -489,19 +519,15 @@ struct Fwd {
         half_t* n1 = alloc(x.rows() * Cin);
         if (!n1) return UV_ERR_STATE;
         RUN(groupnorm(x, skip, rps, u.cfg.norm_eps, p + ".norm1", 1, n1, true));
-        half_t* tp = alloc((long)B * Cout);
-        if (!tp) return UV_ERR_STATE;
-        half_t *tw = W(p + ".time_emb_proj.weight"), *tb = W(p + ".time_emb_proj.bias");
-        if (!tw || !tb) return u.missing_error();
-        RUN(uv_launch_linear_small(emb, tw, tb, tp, B, Cout, 4 * u.cfg.block_out_channels[0], 1, s));
+        auto to = u.temb_off.find(p);
+        UV_REQUIRE(to != u.temb_off.end() && temb_all, "%s: time_emb_proj missing", p.c_str());
         Act n1a{n1, x.imgs, x.H, x.W, Cin}, h;
-        RUN(conv(n1a, nullptr, p + ".conv1", Cout, 9, 1, 0, tp, nullptr, &h));
+        RUN(conv(n1a, nullptr, p + ".conv1", Cout, 9, 1, 0, temb_all + to->second, nullptr, &h, u.temb_total));
         free(n1);
         half_t* n2 = alloc(h.rows() * Cout);
         if (!n2) return UV_ERR_STATE;
         RUN(groupnorm(h, nullptr, rps, u.cfg.norm_eps, p + ".norm2", 1, n2, true));
         free(h.p);
-        free(tp);
         const half_t* res = x.p;
         Act sc{};
         if (u.find(p + ".conv_shortcut.weight")) {
@@ -653,6 +679,12 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
         if (!w1 || !b1 || !w2 || !b2) return missing_error();
         RUN(uv_launch_linear_small(tsin, w1, b1, e1, B, TED, C0, 0, s));
         RUN(uv_launch_linear_small(e1, w2, b2, f.emb, B, TED, TED, 1, s));
+        if (temb_total > 0) {           // resnet.py:349-351 for all resnets at once
+            half_t *wa = W("time_emb_proj#all.weight"), *ba = W("time_emb_proj#all.bias");
+            f.temb_all = f.alloc((long)B * temb_total);
+            if (!wa || !ba || !f.temb_all) return missing_error();
+            RUN(uv_launch_linear_small(f.emb, wa, ba, f.temb_all, B, (int)temb_total, TED, 1, s));
+        }
     }
     // ---- conv_in
     const int CP = (cfg.in_channels + 7) / 8 * 8;
