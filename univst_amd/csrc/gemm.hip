@@ -113,10 +113,11 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
 // ds_write_b128) and reads it back row-major, so residual loads and output stores are 16 B per lane over 320 contiguous bytes.
 // Arithmetic order is that of gemm_epilogue_row (fp32: acc + bias + rowbias + residual, one rounding, then bias2).
 constexpr int EPI_LDW = 164;
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 (&acc)[10][4], float* slab, int mw, int nb, int lane) {
+template <int MJ>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 (&acc)[10][MJ], float* slab, int mw, int nb, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < MJ; ++j) {
 #pragma unroll
         for (int i = 0; i < 10; ++i) *reinterpret_cast<f4*>(&slab[l15 * EPI_LDW + i * 16 + g * 4]) = acc[i][j];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -451,9 +452,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 // operand traffic per flop is 2.2x lower than the 128x128 kernel, which is what lifts the L2-bandwidth ceiling
 // those tiles sit on.  Staging is global_load_lds only (two 72 KB LDS buffers, unpadded 128 B
 // rows, XOR-swizzled chunks), one barrier per 64-wide k tile, 80 MFMAs per wave between barriers.
-template <int MODE>
+template <int MODE, int MJ>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
-    constexpr int NF = 10, BMB = 256, BNB = 320, BK = 64, LDSH = 64;
+    // MJ = 16-row fragments per wave along M: 4 -> 256-row tile, 3 -> 192-row tile (same kernel, chosen per problem so that
+    // the tile count fills whole rounds of the 256 CUs: 49152 and 12288 rows are 256 / 64 tiles of 192)
+    constexpr int NF = 10, BMB = 64 * MJ, BNB = 320, BK = 64, LDSH = 64;
     constexpr int TILE = (BMB + BNB) * LDSH;                 // halfs per buffer (72 KB)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
 
@@ -474,11 +477,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 
     const int rb = tid >> 3;                                  // 0..63
     const int kc = (tid & 7) ^ (rb & 7);                      // logical chunk staged by this lane
-    unsigned xoff[4];
-    int x_iy0[4], x_ix0[4], x_img[4];
-    bool x_ok[4];
+    unsigned xoff[MJ];
+    int x_iy0[MJ], x_ix0[MJ], x_img[MJ];
+    bool x_ok[MJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MJ; ++i) {
         int m = m0 + rb + 64 * i;
         x_ok[i] = m < p.M;
         if (MODE == 0) {
@@ -497,11 +500,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     // (ky, kx) is the row's own base plus a wave-uniform delta, and padding validity is a 9-bit mask per row computed
     // once — 3 VALU per DMA instead of ~25 (the conv kernel issued 149 non-MFMA VALU per 80 MFMAs; tools/pmc_gemm.sh).
     const bool fast_conv = MODE == 1 && p.korder && p.up == 0 && p.taps == 9;
-    int x_pix0[4];
-    unsigned x_mask[4];
+    int x_pix0[MJ];
+    unsigned x_mask[MJ];
     if (MODE == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MJ; ++i) {
             x_pix0[i] = (x_img[i] + x_iy0[i]) * p.Ws + x_ix0[i];
             unsigned mk = 0;
 #pragma unroll
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         if (!(parts & 1)) {
         } else if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) glds16((x_ok[i] && kok) ? p.X + xoff[i] + k0 : zp, Xd + 64 * i * LDSH);
+            for (int i = 0; i < MJ; ++i) glds16((x_ok[i] && kok) ? p.X + xoff[i] + k0 : zp, Xd + 64 * i * LDSH);
         } else if (fast_conv) {
             const int tap_u = __builtin_amdgcn_readfirstlane(tap);             // (tap, slab) are block-uniform in this k order
             const int slab_u = __builtin_amdgcn_readfirstlane(cc - kc * 8);
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             const int ky = tap_u / 3, kx = tap_u - 3 * ky;
             const long delta = (long)(ky * p.Ws + kx) * cs + (src2 ? slab_u - p.C1 : slab_u) + kc * 8;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MJ; ++i) {
                 const bool ok = kok && ((x_mask[i] >> tap_u) & 1u);
                 glds16(ok ? base + (long)x_pix0[i] * cs + delta : zp, Xd + 64 * i * LDSH);
             }
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             const int cs = src2 ? p.C2 : p.C1;
             const int co = src2 ? cc - p.C1 : cc;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MJ; ++i) {
                 int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
                 bool ok = x_ok[i] && kok && iy >= 0 && iy < He && ix >= 0 && ix < We;
                 long pix = (long)(x_img[i] + (iy >> p.up)) * p.Ws + (ix >> p.up);
@@ -588,11 +591,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         }
     };
 
-    f4 acc[NF][4];
+    f4 acc[NF][MJ];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = kt1 - kt0;
     issue_tile(kt0 * BK, 0);
@@ -611,8 +614,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * 160 + i * 16 + l15) * LDSH + ch]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                h8 b = *reinterpret_cast<const h8*>(&Xs[(wm * 64 + j * 16 + l15) * LDSH + ch]);
+            for (int j = 0; j < MJ; ++j) {
+                h8 b = *reinterpret_cast<const h8*>(&Xs[(wm * 16 * MJ + j * 16 + l15) * LDSH + ch]);
 #pragma unroll
                 for (int i = 0; i < NF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][j], 0, 0, 0);
             }
@@ -620,8 +623,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
     if (p.splits > 1) {                   // split-K: raw fp32 partials; splitk_reduce_kernel runs the epilogue
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 64 + j * 16 + l15;
+        for (int j = 0; j < MJ; ++j) {
+            const int m = m0 + wm * 16 * MJ + j * 16 + l15;
             if (m >= p.M) continue;
             float* row = p.partial + ((long)split * p.M + m) * p.N + n0 + wn * 160 + g * 4;
 #pragma unroll
@@ -631,15 +634,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
     if (p.epi_lds) {
         __syncthreads();                  // every wave is done with the operand tiles: smem becomes the transpose scratch
-        gemm_epilogue_lds(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 64, n0 + wn * 160, lane);
+        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane);
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < MJ; ++j) {
         f4 col[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
-        gemm_epilogue_row<NF>(p, col, m0 + wm * 64 + j * 16 + l15, n0 + wn * 160, g);
+        gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MJ + j * 16 + l15, n0 + wn * 160, g);
     }
 }
 
@@ -705,7 +708,14 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     static const int variant0 = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
         static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
-        const long nblk = (long)((p.M + 255) / 256) * (p.N / 320);
+        // tile height: 256 rows, or 192 when that fills whole rounds of the CUs better (49152 x 640 is 384 tiles of 256 = 1.5
+        // rounds but 512 tiles of 192 = 2 exact ones; 12288 x 1280 is 192 vs 256 tiles); 4 % per-tile overhead assumed for 192
+        static const int bm_env = getenv("UNIVST_GEMM_BM") ? atoi(getenv("UNIVST_GEMM_BM")) : 0;     // A/B aid: force 256 / 192
+        const long ncu = uv_num_cus();
+        const long n256 = (long)((p.M + 255) / 256) * (p.N / 320), n192 = (long)((p.M + 191) / 192) * (p.N / 320);
+        const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * 1.04;
+        const bool use192 = bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150);
+        const long nblk = use192 ? n192 : n256;
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
         static const long bigmin_env = getenv("UNIVST_GEMM_BIGMIN") ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 0;
         const long bigmin = bigmin_env ? bigmin_env : 150;   // measured cross-over (tools/bench_gemm_mid.py)
@@ -749,8 +759,12 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                     own_ws = true;
                 }
             }
-            if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0>), dim3((unsigned)(nblk * q.splits)), dim3(512), 0, stream, q);
-            else hipLaunchKernelGGL((gemm_big_kernel<1>), dim3((unsigned)(nblk * q.splits)), dim3(512), 0, stream, q);
+            const dim3 bgrid((unsigned)(nblk * q.splits));
+            if (use192) {
+                if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0, 3>), bgrid, dim3(512), 0, stream, q);
+                else hipLaunchKernelGGL((gemm_big_kernel<1, 3>), bgrid, dim3(512), 0, stream, q);
+            } else if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0, 4>), bgrid, dim3(512), 0, stream, q);
+            else hipLaunchKernelGGL((gemm_big_kernel<1, 4>), bgrid, dim3(512), 0, stream, q);
             if (q.splits > 1) {
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, q);
                 if (own_ws) UV_HIP(hipFreeAsync(q.partial, stream));
