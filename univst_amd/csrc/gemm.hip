@@ -709,11 +709,12 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
         static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
         // tile height: 256 rows, or 192 when that fills whole rounds of the CUs better (49152 x 640 is 384 tiles of 256 = 1.5
-        // rounds but 512 tiles of 192 = 2 exact ones; 12288 x 1280 is 192 vs 256 tiles); 4 % per-tile overhead assumed for 192
+        // rounds but 512 tiles of 192 = 2 exact ones; 12288 x 1280 is 192 vs 256 tiles)
         static const int bm_env = getenv("UNIVST_GEMM_BM") ? atoi(getenv("UNIVST_GEMM_BM")) : 0;     // A/B aid: force 256 / 192
         const long ncu = uv_num_cus();
         const long n256 = (long)((p.M + 255) / 256) * (p.N / 320), n192 = (long)((p.M + 191) / 192) * (p.N / 320);
-        const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * 1.04;
+        // per-row cost of the 192-row tile relative to the 256-row one, measured at equal round counts: convs 0.96-1.0, linears 1.02-1.07
+        const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * (mode == 1 ? 0.99 : 1.05);
         const bool use192 = bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150);
         const long nblk = use192 ? n192 : n256;
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
