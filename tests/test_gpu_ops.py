@@ -158,7 +158,9 @@ def conv_w_ti(w):   # [Co,Ci,3,3] -> [Co,Ci/64,9,64]
 
 
 @pytest.mark.parametrize("C1,C2,Co,H,imgs,stride,up", [(64, 0, 64, 16, 6, 1, False), (128, 64, 96, 12, 6, 2, False),
-                                                         (64, 64, 320, 56, 48, 1, False), (64, 0, 320, 28, 48, 1, True)])
+                                                         (64, 64, 320, 56, 48, 1, False), (64, 0, 320, 28, 48, 1, True),
+                                                         (64, 64, 320, 56, 48, 2, False),      # stride 2 on the 192-row tile (uniform-delta im2col)
+                                                         (128, 0, 640, 30, 48, 1, False)])     # odd image width, 2 column tiles
 def test_conv3x3_tap_inner_order(nat, C1, C2, Co, H, imgs, stride, up):
     x1 = rnd(imgs, C1, H, H, seed=1)
     x2 = rnd(imgs, C2, H, H, seed=2) if C2 else None
