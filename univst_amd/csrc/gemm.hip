@@ -693,6 +693,21 @@ static int uv_num_cus() {
     return n;
 }
 
+// Split-K factor for `ntiles` output tiles, `nk` k tiles each, on `slots` concurrently resident blocks: minimise
+//   ceil(ntiles * s / slots) rounds x ceil(nk / s) k tiles (us_per_ktile each)  +  the fp32 partial traffic (s writes + s reads)
+// — rounds, not raw block counts: 48 tiles x 6 splits = 288 blocks is TWO rounds on 256 CUs, 48 x 5 = 240 is one.
+static int uv_pick_splits(long ntiles, int nk, long slots, int min_ktps, int max_s, double us_per_ktile, double mn_bytes) {
+    int best_s = 1;
+    double best = (double)((ntiles + slots - 1) / slots) * nk * us_per_ktile;
+    for (int s = 2; s <= max_s; ++s) {
+        const int ktps = (nk + s - 1) / s;
+        if (ktps < min_ktps) break;
+        const double t = (double)((ntiles * s + slots - 1) / slots) * ktps * us_per_ktile + 2.0 * s * mn_bytes / 4.0e6;   // 4 TB/s = 4e6 B/us
+        if (t < best * 0.95) { best = t; best_s = s; }
+    }
+    return best_s;
+}
+
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
@@ -725,9 +740,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         static const int splitk_big = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
         if (splitk_big && !nobig && !p.geglu && p.N % 320 == 0 && nblk < bigmin && nblk >= 8 && p.K >= 128 * 64) {   // fp32 partials cost ~35 us: long reductions only
             const int nk = (p.K + 63) / 64;
-            int sp = (int)((256 + nblk - 1) / nblk);
-            if (sp > nk / 24) sp = nk / 24;
-            if (sp > 8) sp = 8;
+            const int sp = uv_pick_splits(nblk, nk, uv_num_cus(), 24, 8, 2.2, (double)p.M * p.N * 4.0);
             if (sp >= 2 && nblk * sp >= 128 && (size_t)sp * p.M * p.N * sizeof(float) <= UV_SPLITK_WS_BYTES) bsplits = sp;
         }
         if (!nobig && p.N % 320 == 0 && (nblk >= bigmin || bsplits > 1) && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
@@ -793,9 +806,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     static const int splitk = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
     if (splitk && variant0 == 5 && !p.geglu && p.N % 4 == 0 && nt < 384) {
         const int nk = (p.K + 63) / 64;
-        int s = (512 + nt - 1) / nt;
-        if (s > nk / 4) s = nk / 4;
-        if (s > 16) s = 16;
+        const int s = uv_pick_splits(nt, nk, 2L * uv_num_cus(), 4, 16, 1.0, (double)p.M * p.N * 4.0);     // two resident blocks per CU
         if (s >= 2) {
             q.ktps = (nk + s - 1) / s;
             q.splits = (nk + q.ktps - 1) / q.ktps;
