@@ -227,7 +227,7 @@ def main():
         sync()
         out["config"]["extra_skip_dead_branches_frames_per_s"] = round(F_total / (time.perf_counter() - t0), 4)
         out["config"]["extra_skip_dead_branches_note"] = ("same 50-step transfer, branches 0/1 dropped once the PnP window closes (i > 25): "
-                                                          "bitwise-identical latents (tests), 102 instead of 150 branch-steps; NOT the headline value")
+                                                          "same latents up to fp32 summation order (tests: >= 60 dB), 102 instead of 150 branch-steps; NOT the headline value")
 
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:

@@ -33,7 +33,6 @@ def lin(M, N, K, geglu=False, res=False, tag=""):
     print(f"linear M={M} N={N} K={K} geglu={int(geglu)} {tag}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF {by / ms / 1e6:7.1f} GB/s")
 
 if __name__ == "__main__":
-    print("variant", os.environ.get("UNIVST_GEMM_VARIANT", "0"))
     conv(320, 320, 64); conv(640, 320, 64, C2=320); conv(640, 640, 32); conv(1280, 1280, 16); conv(1280, 1280, 8); conv(1280, 1280, 8, C2=1280)
     lin(196608, 320, 320, res=True, tag="L0 proj"); lin(196608, 960, 320, tag="L0 qkv"); lin(196608, 2560, 320, geglu=True, tag="L0 ff1")
     lin(196608, 320, 1280, res=True, tag="L0 ff2"); lin(49152, 5120, 640, geglu=True, tag="L1 ff1"); lin(49152, 640, 2560, res=True, tag="L1 ff2")

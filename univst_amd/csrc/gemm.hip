@@ -193,22 +193,22 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
 
 constexpr int BM_DEFAULT = 128;
 
-// BK: k extent of one LDS tile (32 or 64).  DBUF: two LDS buffers -> one barrier per k tile, the next tile's global
-// loads stay in flight under the MFMAs and are written to the other buffer right after them.
-template <int NF, int MODE, int BK, bool DBUF, bool GLDS, int MF = 4>
+// Block tile BM x BN, 256 threads = 4 waves as 2(n) x 2(m); each wave NF x MF MFMA fragments.
+// Operand A (weights, LDS [BN][64]) rows n; operand B (activations, LDS [BM][64]) rows m.
+// Staging is global_load_lds only: it writes lane-linear 16-byte pieces, so LDS rows are UNPADDED 128 B and the 16-byte
+// chunk index is XOR-swizzled with (row & 7) — applied to the per-lane SOURCE address and to the fragment reads.  Two LDS
+// buffers, one barrier per 64-wide k tile; the next tile's DMA flies under this tile's MFMAs.  (Register-staged variants of
+// this kernel were measured earlier in the round: the ds_write pass + its second barrier cost half the time)
+template <int NF, int MODE, int MF = 4>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
+    constexpr int BK = 64, LDSH = 64;
     constexpr int BN = NF * 32;
     constexpr int BM = 32 * MF;          // MF = 4: 128-row tile; MF = 2: 64-row tile for small-M problems that would leave CUs idle
-    // register-staged path: rows padded (80 halfs for BK 64 / 48 for BK 32) -> conflict-free b128 reads.
-    // GLDS path: global_load_lds writes lane-linear 16-byte pieces, so rows are UNPADDED 128 B and the 16-byte chunk
-    // index is XOR-swizzled with (row & 7) — applied to the per-lane SOURCE address and to the fragment reads.
-    constexpr int LDSH = GLDS ? BK : lds_stride_bytes(BK * 2) / 2;
     constexpr int CPR = BK / 8;                            // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;                         // rows staged per pass
-    constexpr int XL = BM / RPP, WL = (BN + RPP - 1) / RPP;   // staging loads per thread
+    constexpr int XL = BM / RPP, WL = (BN + RPP - 1) / RPP;   // staging DMAs per thread
     constexpr int TILE = (BM + BN) * LDSH;
-    static_assert(!GLDS || BK == 64, "GLDS path is written for BK = 64");
-    __shared__ __attribute__((aligned(16))) half_t smem[((DBUF || GLDS) ? 2 : 1) * TILE];
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
     // ---- per-thread staging geometry: chunk kc (8 halfs) of rows rb + 32*i
     const int rb = tid / CPR;
-    const int kc = GLDS ? ((tid % CPR) ^ (rb & 7)) : (tid % CPR);     // logical 16-byte chunk this lane stages
+    const int kc = (tid % CPR) ^ (rb & 7);                 // logical 16-byte chunk this lane stages
     const half_t* xptr[XL];
     int x_iy0[XL], x_ix0[XL], x_img[XL];
     bool x_ok[XL];
@@ -269,35 +269,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
     }
 
-    h8 xr[XL], wr[WL];
-    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto load_tile = [&](int k0) {
-        const bool kok = (k0 + kc * 8) < p.K;
-        if (MODE == 0) {
-#pragma unroll
-            for (int i = 0; i < XL; ++i)
-                xr[i] = (x_ok[i] && kok) ? *reinterpret_cast<const h8*>(xptr[i] + k0) : zero8;
-        } else {
-            const int ky = (p.taps == 9) ? tap / 3 : 0;
-            const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
-            const int He = p.Hs << p.up, We = p.Ws << p.up;
-            const bool src2 = cc >= p.C1;
-            const half_t* base = src2 ? p.X2 : p.X;
-            const int cs = src2 ? p.C2 : p.C1;
-            const int co = src2 ? cc - p.C1 : cc;
-#pragma unroll
-            for (int i = 0; i < XL; ++i) {
-                int iy = x_iy0[i] + ky, ix = x_ix0[i] + kx;
-                bool ok = x_ok[i] && kok && iy >= 0 && iy < He && ix >= 0 && ix < We;
-                long pix = (long)(x_img[i] + (iy >> p.up)) * p.Ws + (ix >> p.up);
-                xr[i] = ok ? *reinterpret_cast<const h8*>(base + pix * cs + co) : zero8;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < WL; ++i)
-            wr[i] = (w_ok[i] && kok) ? *reinterpret_cast<const h8*>(wptr[i] + k0) : zero8;
-    };
     auto advance_k = [&]() {
         if (MODE == 1) {
             if (p.korder) {            // tap-inner: next tap of the same 64-channel slab, then the next slab
@@ -308,23 +279,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             }
         }
     };
-    auto store_tile = [&](int buf) {
-        half_t* Xs = smem + buf * TILE;
-        half_t* Ws = Xs + BM * LDSH;
-#pragma unroll
-        for (int i = 0; i < XL; ++i)
-            *reinterpret_cast<h8*>(&Xs[(rb + RPP * i) * LDSH + kc * 8]) = xr[i];
-#pragma unroll
-        for (int i = 0; i < WL; ++i)
-            if ((BN % RPP == 0) || (rb + RPP * i) < BN) *reinterpret_cast<h8*>(&Ws[(rb + RPP * i) * LDSH + kc * 8]) = wr[i];
-    };
-
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     auto glds16 = [&](const half_t* src, half_t* dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    auto issue_tile = [&](int k0, int buf) {      // GLDS: global -> LDS directly (no VGPR round trip, no ds_write)
+    auto issue_tile = [&](int k0, int buf) {      // global -> LDS directly (no VGPR round trip, no ds_write)
         half_t* Xd = smem + buf * TILE + wave_u * 8 * LDSH;
         half_t* Wd = Xd + BM * LDSH;
         const bool kok = (k0 + kc * 8) < p.K;
@@ -358,54 +318,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         for (int j = 0; j < MF; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = kt1 - kt0;            // k tiles of THIS block (all of them unless split-K)
-    if (GLDS) {
-        issue_tile(kt0 * BK, 0);
-        advance_k();
-    } else {
-        load_tile(kt0 * BK);
-        advance_k();
-        store_tile(0);
-        __syncthreads();
-    }
-
+    issue_tile(kt0 * BK, 0);
+    advance_k();
+    const int sw = l15 & 7;
     for (int kt = 0; kt < nk; ++kt) {
-        const half_t* Xs = smem + ((DBUF || GLDS) ? (kt & 1) * TILE : 0);
+        const half_t* Xs = smem + (kt & 1) * TILE;
         const half_t* Ws = Xs + BM * LDSH;
-        if (GLDS) {
-            __syncthreads();              // (vmcnt(0) + barrier) tile kt landed for every wave; buffer (kt+1)&1 is free
-            if (kt + 1 < nk) {            // next tile's DMA flies under this tile's MFMAs
-                issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1);
-                advance_k();
-            }
-        } else if (kt + 1 < nk) {                 // next tile's global loads fly under this tile's MFMAs
-            load_tile((kt0 + kt + 1) * BK);
+        __syncthreads();                  // (vmcnt(0) + barrier) tile kt landed for every wave; buffer (kt+1)&1 is free
+        if (kt + 1 < nk) {                // next tile's DMA flies under this tile's MFMAs
+            issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1);
             advance_k();
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
+            const int ch = ((ks * 4 + g) ^ sw) * 8;
             h8 a[NF], b[MF];
 #pragma unroll
-            for (int i = 0; i < NF; ++i)
-                a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * NF * 16 + i * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
+            for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * NF * 16 + i * 16 + l15) * LDSH + ch]);
 #pragma unroll
-            for (int j = 0; j < MF; ++j)
-                b[j] = *reinterpret_cast<const h8*>(&Xs[(wm * 16 * MF + j * 16 + l15) * LDSH + (GLDS ? (((ks * 4 + g) ^ (l15 & 7)) * 8) : (ks * 32 + g * 8))]);
+            for (int j = 0; j < MF; ++j) b[j] = *reinterpret_cast<const h8*>(&Xs[(wm * 16 * MF + j * 16 + l15) * LDSH + ch]);
 #pragma unroll
             for (int i = 0; i < NF; ++i)
 #pragma unroll
                 for (int j = 0; j < MF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (GLDS) {
-        } else if (DBUF) {
-            if (kt + 1 < nk) store_tile((kt + 1) & 1);
-            __syncthreads();
-        } else {
-            __syncthreads();
-            if (kt + 1 < nk) {
-                store_tile(0);
-                __syncthreads();
-            }
         }
     }
 
@@ -720,7 +656,6 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         UV_REQUIRE(p.K == p.taps * (p.C1 + p.C2), "conv: K=%d != taps*(C1+C2)", p.K);
         UV_REQUIRE(!p.korder || (p.taps == 9 && p.C1 % 64 == 0 && p.C2 % 64 == 0), "conv: tap-inner k order needs taps=9 and 64-channel slabs");
     }
-    static const int variant0 = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
         static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
         // tile height: 256 rows, or 192 when that fills whole rounds of the CUs better (49152 x 640 is 384 tiles of 256 = 1.5
@@ -795,7 +730,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     // UNIVST_GEMM_SMALLM (A/B aid): 0 = never, 1 = whenever the 128-row tiles are < 2 per CU, 2 (default) = convs only when
     // split-K cannot supply the parallelism instead (short K); linears always (measured: tools/bench_gemm_mid.py)
     static const int smallm_mode = getenv("UNIVST_GEMM_SMALLM") ? atoi(getenv("UNIVST_GEMM_SMALLM")) : 2;
-    const bool small_m = variant0 == 5 && !nf5 && nt < 2 * uv_num_cus() && p.M > 64 && smallm_mode != 0 &&
+    const bool small_m = !nf5 && nt < 2 * uv_num_cus() && p.M > 64 && smallm_mode != 0 &&
                          (smallm_mode == 1 || mode == 0 || p.geglu || (p.K + 63) / 64 < 16);
     if (small_m) nt = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
@@ -804,7 +739,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     q.splits = 1;
     bool own_ws = false;
     static const int splitk = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
-    if (splitk && variant0 == 5 && !p.geglu && p.N % 4 == 0 && nt < 384) {
+    if (splitk && !p.geglu && p.N % 4 == 0 && nt < 384) {
         const int nk = (p.K + 63) / 64;
         const int s = uv_pick_splits(nt, nk, 2L * uv_num_cus(), 4, 16, 1.0, (double)p.M * p.N * 4.0);     // two resident blocks per CU
         if (s >= 2) {
@@ -821,27 +756,18 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         }
     }
     dim3 grid(nt * q.splits), block(256);
-    static const int variant = getenv("UNIVST_GEMM_VARIANT") ? atoi(getenv("UNIVST_GEMM_VARIANT")) : 5;
     uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
                   2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
-#define UV_GEMM_LAUNCH(BK_, DB_, GL_)                                                                       \
-    do {                                                                                                   \
-        if (mode == 0) {                                                                                   \
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, BK_, DB_, GL_>), grid, block, 0, stream, q);    \
-            else hipLaunchKernelGGL((gemm_kernel<4, 0, BK_, DB_, GL_>), grid, block, 0, stream, q);        \
-        } else {                                                                                           \
-            if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1, BK_, DB_, GL_>), grid, block, 0, stream, q);    \
-            else hipLaunchKernelGGL((gemm_kernel<4, 1, BK_, DB_, GL_>), grid, block, 0, stream, q);        \
-        }                                                                                                  \
-    } while (0)
-    // UNIVST_GEMM_VARIANT (A/B aid): 5 = global_load_lds staging (default); 0 = register-staged, one LDS buffer;
-    // 1 = register-staged, two LDS buffers.  The DMA path won every shape except none (tools/bench_gemm.py).
-    if (variant == 5 && small_m) {
-        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 64, false, true, 2>), grid, block, 0, stream, q);
-        else hipLaunchKernelGGL((gemm_kernel<4, 1, 64, false, true, 2>), grid, block, 0, stream, q);
-    } else if (variant == 5) UV_GEMM_LAUNCH(64, false, true);
-    else if (variant == 1) UV_GEMM_LAUNCH(64, true, false);
-    else UV_GEMM_LAUNCH(64, false, false);
+    if (small_m) {
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 2>), grid, block, 0, stream, q);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1, 2>), grid, block, 0, stream, q);
+    } else if (mode == 0) {
+        if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0>), grid, block, 0, stream, q);
+        else hipLaunchKernelGGL((gemm_kernel<4, 0>), grid, block, 0, stream, q);
+    } else {
+        if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 1>), grid, block, 0, stream, q);
+        else hipLaunchKernelGGL((gemm_kernel<4, 1>), grid, block, 0, stream, q);
+    }
     if (q.splits > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, q);
         if (own_ws) UV_HIP(hipFreeAsync(q.partial, stream));
