@@ -34,6 +34,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo stages through the host, bring-up only)")
+    ap.add_argument("--emulate-rank", default=None, metavar="R/W",
+                    help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
+                         "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-skip-dead-branches-leg", action="store_true",
@@ -132,7 +135,14 @@ def main():
     from univst_amd.parallel import FrameShard
 
     F_total, h = a.frames, a.latent
-    shard = FrameShard(rank, world, F_total)
+    emu = None
+    if a.emulate_rank and world == 1:
+        from univst_amd.parallel import NullComm
+        er, ew = (int(v) for v in a.emulate_rank.split("/"))
+        emu = (er, ew)
+        shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew))
+    else:
+        shard = FrameShard(rank, world, F_total)
     unet = synth.build_unet(device=dev, seed=33)
     pipe = Pipe(unet, DDIMScheduler())
     pipe.scheduler.set_timesteps(50)
@@ -141,8 +151,9 @@ def main():
     content = [shard.slice_frames(t) for t in content]
     style = [shard.slice_frames(t) for t in style]
     shard.attach(unet)
-    lat = pnp_utils.latent_adain(content[50], style[50]) if world == 1 else shard.latent_adain(content[50], style[50])
-    step = make_step_fn(pipe, content, style, text3, None) if world == 1 else shard.make_step_fn(pipe, content, style, text3)
+    sharded = world > 1 or emu is not None
+    lat = shard.latent_adain(content[50], style[50]) if sharded else pnp_utils.latent_adain(content[50], style[50])
+    step = shard.make_step_fn(pipe, content, style, text3) if sharded else make_step_fn(pipe, content, style, text3, None)
 
     def sync():
         torch.cuda.synchronize()
@@ -171,7 +182,7 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"sd15_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim", "frames": F_total,
-                   "latent": [1, 4, F_total, h, h], "branches": 3, "parallelism": "single" if world == 1 else f"frames{world}",
+                   "latent": [1, 4, F_total, h, h], "branches": 3, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
                    "weights": "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16"},
     }
 
@@ -218,7 +229,7 @@ def main():
         out["config"]["algorithmic_tflop_per_step_executed"] = round(tot_flops / 1e12, 2)
         out["roofline"]["whole_step_tflops"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12, 1)
 
-    if not a.no_skip_dead_branches_leg and world == 1 and a.steps >= 50:
+    if not a.no_skip_dead_branches_leg and world == 1 and emu is None and a.steps >= 50:
         from univst_amd import engine
         sync()
         t0 = time.perf_counter()
@@ -230,7 +241,7 @@ def main():
                                                           "same latents up to fp32 summation order (tests: >= 60 dB), 102 instead of 150 branch-steps; NOT the headline value")
 
     if rank == 0:
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and emu is None:
             out["cpu_baseline"] = cpu_baseline(F_total, unet)
         print(json.dumps(out))
     if dist is not None:

@@ -197,6 +197,24 @@ class HostStagedDistComm(TorchDistComm):
             recv_prev.copy_(rp)
 
 
+class NullComm:
+    """diagnostic stand-in (``bench.py --emulate-rank r/w``): every collective returns at once, so ONE process on one GPU
+    runs exactly the kernels, pack/unpack copies and host callbacks of rank r of a w-GPU job — everything except the wire.
+    Results are meaningless (nothing is exchanged); only the timing is used."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def all_reduce_sum(self, t):
+        pass
+
+    def all_gather(self, t):
+        return [t for _ in range(self.world)]
+
+    def halo_and_broadcast(self, send_last, first, recv_prev, recv_first):
+        pass
+
+
 class ThreadLoopbackComm:
     """`world` host threads of ONE process play the ranks (each with its own native UNet handle and its own HIP stream
     on the same GPU).  Collectives are rendezvous on a threading.Barrier plus device copies — the same call sites and
