@@ -302,6 +302,8 @@ def test_attention_d40_long_reference_jumps(nat):
     k[0, 70] = q[0, 9] * 5
     k[0, 2100] = q[0, 2000] * 4         # inside the tail tile
     q[0, 300] = -k[0, :64].mean(0) * 30  # a query whose early scores are all strongly negative (negative first reference)
+    k[0, :32] = k[0, 3]                  # ... and one whose first 32 scores are all about -145 in log2 units (2^145 overflows fp32)
+    q[0, 400] = -k[0, 3] * 16
     src = torch.zeros(1, 1, dtype=torch.int32).cuda()
     qp, qref = prescaled(q, d)
     close(nat.attention(qp, k, v, src, heads, q_prescaled=True), sdpa_ref(qref, k, v, heads), rtol=4e-3)

@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
                     m = max3f(m, o32, o32);
                     float delta = floorf(m * 64.f + 0.5f) * (1.f / 64.f);          // shifted row max, quantised
                     if (!first) delta = fmaxf(delta, 0.f);
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    // (first reference: O^T is still zero, and 2^-delta overflows for a strongly negative first row max — 0 * inf)
+                    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
                     mrun[qb] += delta;
                     set_shift(qb, mrun[qb]);
 #pragma unroll
