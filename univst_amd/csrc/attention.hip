@@ -384,12 +384,17 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         }
         if (FOLD && g == 1) qf[qb][1][2] = (half_t)lw_cur;        // column 42: + log2 multiplicity of the source
     }
-    auto set_shift = [&](int qb, float M) {                       // columns 40 / 41 of Q' <- -M (FOLD)
+    // columns 40 / 41 of Q' <- -M (FOLD).  Returns the reference the MFMA will REALLY subtract: -(fp16(-hi) + fp16(-lo)), equal
+    // to M whenever |M| < 16384 (hi a multiple of 8, lo a multiple of 1/64 below 8 are exact in fp16); beyond that the
+    // bookkeeping follows the rounded value, so scores, O^T and the denominator stay on one common scale.
+    auto set_shift = [&](int qb, float M) -> float {
         const float hi = floorf(M * 0.125f) * 8.f, lo = M - hi;
+        const half_t hh = (half_t)(-hi), lh = (half_t)(-lo);
         if (g == 1) {
-            qf[qb][1][0] = (half_t)(-hi);
-            qf[qb][1][1] = (half_t)(-lo);
+            qf[qb][1][0] = hh;
+            qf[qb][1][1] = lh;
         }
+        return -((float)hh + (float)lh);
     };
 
     f4 o[DV16][QB];
@@ -566,10 +571,11 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
                     m = max3f(m, o32, o32);
                     float delta = floorf(m * 64.f + 0.5f) * (1.f / 64.f);          // shifted row max, quantised
                     if (!first) delta = fmaxf(delta, 0.f);
+                    const float mnew = set_shift(qb, mrun[qb] + delta);
+                    delta = mnew - mrun[qb];
+                    mrun[qb] = mnew;
                     // (first reference: O^T is still zero, and 2^-delta overflows for a strongly negative first row max — 0 * inf)
                     const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
-                    mrun[qb] += delta;
-                    set_shift(qb, mrun[qb]);
 #pragma unroll
                     for (int kb = 0; kb < 2; ++kb) {
                         sc[kb][qb][0] -= delta; sc[kb][qb][1] -= delta; sc[kb][qb][2] -= delta; sc[kb][qb][3] -= delta;
