@@ -133,6 +133,80 @@ def main():
     gold["g1_latent_adain"] = dict(cnt=lc, sty=ls, out=ref_pnp.latent_adain(lc, ls))
     chk("latent_adain", gold["g1_latent_adain"]["out"], unet_ref.latent_adain(lc, ls))
 
+    # ---- G2 / G3 / G4: component-level pins: the reference's own modules, randomly initialised from a seed,
+    # against the oracle functions driven with the SAME parameters (state_dict under the prefix "m")
+    from backbones.video_diffusion_sd.models.attention import (SparseCausalAttention, SpatioTemporalTransformerBlock,
+                                                               SpatioTemporalTransformerModel)
+    from backbones.video_diffusion_sd.models.resnet import (PseudoConv3d, ResnetBlockPseudo3D, UpsamplePseudo3D,
+                                                            DownsamplePseudo3D)
+
+    def seeded(module, seed):
+        gg = torch.Generator().manual_seed(seed)
+        for prm in module.parameters():          # every parameter non-trivial (incl. the zero / dirac temporal ones)
+            prm.data = (torch.randn(prm.shape, generator=gg) * (0.2 if prm.dim() > 1 else 0.1)
+                        + (1.0 if (prm.dim() == 1 and "norm" in "") else 0.0))
+        return module.eval()
+
+    def sd_of(module):
+        return {"m." + k: v.clone() for k, v in module.state_dict().items()}
+
+    gg = torch.Generator().manual_seed(202)
+    # G3: SparseCausalAttention, F = 4, the three index modes the code base uses
+    sca = seeded(SparseCausalAttention(query_dim=64, heads=8, dim_head=8), 1)
+    x3 = torch.randn(3 * 4, 16, 64, generator=gg)
+    g3 = {}
+    for tag, index in (("stock", [-1, 0, "first"]), ("pnp", [-1, "first"]), ("first_only", ["first"])):
+        y = sca(x3, clip_length=4, SparseCausalAttention_index=index)
+        q, k, v = (unet_ref._lin(sd_of(sca), "m." + n, x3, bias=False) for n in ("to_q", "to_k", "to_v"))
+        mine = unet_ref._lin(sd_of(sca), "m.to_out.0", unet_ref.sdpa(q, unet_ref.sparse_causal_gather(k, 4, index),
+                                                                      unet_ref.sparse_causal_gather(v, 4, index), 8))
+        chk(f"sparse_causal_{tag}", y, mine)
+        g3[tag] = y
+    chk("sparse_causal_stock_attn1_forward", g3["stock"], unet_ref.attn1_forward(sd_of(sca), "m", x3, 4, 8, None))
+    gold["g3_sparse_causal"] = dict(x=x3, out=g3, params=sd_of(sca))
+    # G2: the PnP closure (pnp_utils.py:20-100) patched onto that module through a minimal fake module tree
+    tb = types.SimpleNamespace(attn1=sca, attn2=types.SimpleNamespace())     # register_time also pokes attn2.idx
+    at = types.SimpleNamespace(transformer_blocks=[tb])
+    fake = types.SimpleNamespace(unet=types.SimpleNamespace(up_blocks=[types.SimpleNamespace(attentions=[at, at, at]) for _ in range(4)]))
+    ref_pnp.register_spatial_attention_pnp(fake)
+    g2 = {}
+    for idx in (0, 13, 25, 26):
+        ref_pnp.register_time(fake, idx)
+        y = sca.forward(x3, clip_length=4)
+        chk(f"pnp_closure_idx{idx}", y, unet_ref.attn1_forward(sd_of(sca), "m", x3, 4, 8, dict(idx=idx)))
+        g2[f"idx{idx}"] = y
+    del sca.forward                                   # drop the instance-level patch
+    gold["g2_pnp_closure"] = dict(out=g2)             # (same x and params as g3)
+    # G4: pseudo-3D conv / ResBlock (5-D GroupNorm) / up / down, transformer block / model at C = 32
+    g4 = {}
+    x5 = torch.randn(2, 32, 3, 8, 8, generator=gg)
+    temb = torch.randn(2, 128, generator=gg)
+    conv = seeded(PseudoConv3d(32, 48, kernel_size=3, padding=1), 2)
+    g4["conv"] = conv(x5)
+    chk("pseudo_conv3d", g4["conv"], unet_ref.pseudo_conv3d(sd_of(conv), "m", x5, exact_temporal=True))
+    res = seeded(ResnetBlockPseudo3D(in_channels=32, out_channels=64, temb_channels=128, groups=8, eps=1e-5), 3)
+    g4["resnet"] = res(x5, temb)
+    chk("resnet_block", g4["resnet"], unet_ref.resnet_block(sd_of(res), "m", x5, temb, 8, 1e-5, exact_temporal=True))
+    up = seeded(UpsamplePseudo3D(32, use_conv=True, out_channels=32), 4)
+    g4["up"] = up(x5)
+    chk("upsample", g4["up"], unet_ref.upsample(sd_of(up), "m", x5, exact_temporal=True))
+    down = seeded(DownsamplePseudo3D(32, use_conv=True, out_channels=32, padding=1, name="op"), 5)
+    g4["down"] = down(x5)
+    chk("downsample", g4["down"], unet_ref.pseudo_conv3d(sd_of(down), "m.op" if "m.op.weight" in sd_of(down) else "m.conv", x5,
+                                                        stride=2, padding=1, exact_temporal=True))
+    ctx4 = torch.randn(2 * 3, 77, 24, generator=gg)
+    blk = seeded(SpatioTemporalTransformerBlock(32, 4, 8, cross_attention_dim=24), 6)
+    xt = torch.randn(2 * 3, 64, 32, generator=gg)
+    g4["block"] = blk(xt, encoder_hidden_states=ctx4, clip_length=3)
+    chk("transformer_block", g4["block"], unet_ref.transformer_block(sd_of(blk), "m", xt, ctx4, 3, 4, None, exact_temporal=True))
+    tm = seeded(SpatioTemporalTransformerModel(num_attention_heads=4, attention_head_dim=8, in_channels=32, norm_num_groups=8,
+                                               cross_attention_dim=24), 7)
+    g4["model"] = tm(x5, encoder_hidden_states=ctx4[:2]).sample
+    chk("transformer_model", g4["model"], unet_ref.transformer_model(sd_of(tm), "m", x5, ctx4[:2], 4, 8, None, exact_temporal=True))
+    gold["g4_components"] = dict(x5=x5, temb=temb, xt=xt, ctx=ctx4, out=g4,
+                                 params=dict(conv=sd_of(conv), resnet=sd_of(res), up=sd_of(up), down=sd_of(down), block=sd_of(blk),
+                                             model=sd_of(tm)))
+
     # ---- G5: tiny UNet, three branches, PnP registered, idx in {0, 25, 26}; + feature dump; + no-PnP B=1
     cfg = unet_ref.TINY_CONFIG
     F_, h_, w_ = 4, 16, 16

@@ -20,6 +20,36 @@ def test_adains(golden):
     assert rel(unet_ref.latent_adain(g["cnt"], g["sty"]), g["out"]) < TOL
 
 
+def test_sparse_causal_and_pnp_closure_components(golden):
+    """G3 / G2: the reference's SparseCausalAttention (three index modes) and its PnP closure patched onto it
+    (pnp_utils.py:20-100, idx 0 / 13 / 25 inside the window, 26 outside) vs the oracle with the same parameters."""
+    g = golden("g3_sparse_causal")
+    x, sd = g["x"], g["params"]
+    for tag, index in (("stock", [-1, 0, "first"]), ("pnp", [-1, "first"]), ("first_only", ["first"])):
+        q, k, v = (unet_ref._lin(sd, "m." + n, x, bias=False) for n in ("to_q", "to_k", "to_v"))
+        y = unet_ref._lin(sd, "m.to_out.0", unet_ref.sdpa(q, unet_ref.sparse_causal_gather(k, 4, index),
+                                                           unet_ref.sparse_causal_gather(v, 4, index), 8))
+        assert rel(y, g["out"][tag]) < TOL
+    assert rel(unet_ref.attn1_forward(sd, "m", x, 4, 8, None), g["out"]["stock"]) < TOL
+    g2 = golden("g2_pnp_closure")
+    for idx in (0, 13, 25, 26):
+        assert rel(unet_ref.attn1_forward(sd, "m", x, 4, 8, dict(idx=idx)), g2["out"][f"idx{idx}"]) < TOL
+
+
+def test_unet_building_blocks(golden):
+    """G4: PseudoConv3d, ResnetBlockPseudo3D (5-D GroupNorm), Up/DownsamplePseudo3D, SpatioTemporalTransformerBlock / Model
+    of the reference at C = 32 with NON-trivial temporal parameters, vs the oracle functions."""
+    g = golden("g4_components")
+    x5, temb, xt, ctx, out, prm = g["x5"], g["temb"], g["xt"], g["ctx"], g["out"], g["params"]
+    assert rel(unet_ref.pseudo_conv3d(prm["conv"], "m", x5, exact_temporal=True), out["conv"]) < TOL
+    assert rel(unet_ref.resnet_block(prm["resnet"], "m", x5, temb, 8, 1e-5, exact_temporal=True), out["resnet"]) < TOL
+    assert rel(unet_ref.upsample(prm["up"], "m", x5, exact_temporal=True), out["up"]) < TOL
+    dp = "m.op" if "m.op.weight" in prm["down"] else "m.conv"
+    assert rel(unet_ref.pseudo_conv3d(prm["down"], dp, x5, stride=2, padding=1, exact_temporal=True), out["down"]) < TOL
+    assert rel(unet_ref.transformer_block(prm["block"], "m", xt, ctx, 3, 4, None, exact_temporal=True), out["block"]) < TOL
+    assert rel(unet_ref.transformer_model(prm["model"], "m", x5, ctx[:2], 4, 8, None, exact_temporal=True), out["model"]) < TOL
+
+
 @pytest.mark.parametrize("tag,trivial", [("trivial", True), ("general", False)])
 def test_tiny_unet(golden, tag, trivial):
     cfg = unet_ref.TINY_CONFIG
