@@ -13,6 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats -- python b
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/raw/fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/raw/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/raw/write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/raw/write.log 2>&1
 bash tools/pmc_attn.sh $O/raw/attn > $O/round1_pmc_attn_d40_sq.txt 2>&1
+bash tools/pmc_gemm.sh $O/raw/gemm 2>&1 | grep -E "^SQ_" > $O/round1_pmc_conv_tile_sq.txt
 python tools/summarize_profiles.py $O
 rm -rf $O/raw/stats/*/*_agent_info.csv
 ls -la $O
