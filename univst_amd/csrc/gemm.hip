@@ -647,7 +647,6 @@ static int uv_pick_splits(long ntiles, int nk, long slots, int min_ktps, int max
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
-    UV_REQUIRE(p.N % 4 == 0 || true, "gemm: N");
     if (mode == 0) {
         UV_REQUIRE(p.ldx % 8 == 0, "gemm: ldx=%ld must be a multiple of 8", p.ldx);
     } else {
