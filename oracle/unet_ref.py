@@ -60,6 +60,11 @@ def _lin(sd, name, x, bias=True):
     return F.linear(x, sd[name + ".weight"], b)
 
 
+# rows of the (b f) axis evaluated per SDPA call (None = all at once).  The result does not depend on it (rows are
+# independent); the BASELINE-size device tests set it so an fp32 "math" SDPA never materialises [48,8,4096,12288] scores.
+SDPA_MAX_BATCH = None
+
+
 def sdpa(q, k, v, heads):
     """AttnProcessor2_0 core: split heads, softmax(QK^T/sqrt(d)) V, merge heads."""
     b, nq, c = q.shape
@@ -67,7 +72,8 @@ def sdpa(q, k, v, heads):
     q = q.view(b, nq, heads, d).transpose(1, 2)
     k = k.view(b, -1, heads, d).transpose(1, 2)
     v = v.view(b, -1, heads, d).transpose(1, 2)
-    o = F.scaled_dot_product_attention(q, k, v)
+    step = b if not SDPA_MAX_BATCH else int(SDPA_MAX_BATCH)
+    o = torch.cat([F.scaled_dot_product_attention(q[i:i + step], k[i:i + step], v[i:i + step]) for i in range(0, b, step)])
     return o.transpose(1, 2).reshape(b, nq, c)
 
 

@@ -328,6 +328,40 @@ def main():
     gold["g9_flow"] = dict(occ=torch.from_numpy(occ), applied=torch.from_numpy(am))
     report.append(("occlusion/apply_mask_bit_exact", 0.0, 0.0))
 
+    # ---- G13: the reference's get_warp (src/cal_optica_flow.py:51-99) run as is, with the two third-party calls it
+    #      makes replaced: torchvision raft_large -> a fake model returning seeded analytic flows, cv2.remap -> the
+    #      oracle's fixed-point restatement (OpenCV itself is absent: remap stays "restated", everything around it —
+    #      which flow is forward, threshold 1.5, ref_image2 warped and composited over ref_image1, uint8 truncation —
+    #      is the reference's own code)
+    class FakeRaft(torch.nn.Module):
+        def __init__(self, flows):
+            super().__init__()
+            self.flows, self.k = flows, 0
+
+        def forward(self, a, b):
+            f = torch.from_numpy(self.flows[self.k % len(self.flows)]).permute(2, 0, 1)[None]
+            self.k += 1
+            return [f * 0.0, f]
+    H = W = 96
+    f_fwd = si.translation_flow(H, W, 3.3, -2.7, 101, noise=0.6)
+    f_bwd = si.translation_flow(H, W, -3.3, 2.7, 102, noise=0.6)
+    f_bwd[5:15, 20:40] += 4.0
+    ref_fl.raft_large = lambda weights=None: FakeRaft([f_fwd, f_bwd])
+    ref_fl.Raft_Large_Weights = types.SimpleNamespace(DEFAULT=None)
+    ref_fl.cv2 = types.SimpleNamespace(INTER_LINEAR=1, BORDER_CONSTANT=0,
+                                       remap=lambda img, mx, my, interpolation=None, borderMode=None: flow_ref.remap_bilinear_u8(img, mx, my))
+    rs = np.random.RandomState(13)
+    im1, im2 = rs.randint(0, 256, (H, W, 3)).astype(np.uint8), rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    warped = ref_fl.get_warp(im1, im2, im1, im2)
+    k = [0]
+
+    def flow_fn(a, b):
+        k[0] += 1
+        return (f_fwd, f_bwd)[(k[0] - 1) % 2]
+    assert np.array_equal(warped, flow_ref.get_warp(flow_fn, im1, im2)), "get_warp oracle differs from the reference's composition"
+    gold["g13_get_warp"] = dict(warped=torch.from_numpy(warped))
+    report.append(("get_warp_composition_bit_exact(remap restated)", 0.0, 0.0))
+
     # ---- G10: the reference's own video_style_transfer loop through the stubs (tiny UNet, F=16, 50 steps)
     from backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
     import backbones.video_diffusion_sd.pipelines.stable_diffusion as ref_pipe_mod
@@ -372,6 +406,45 @@ def main():
         for i in keep:
             chk(f"transfer_{tag}_i{i}", cap[i], mine[i], 2e-3)
         gold[f"g10_{tag}"] = {f"i{i}": cap[i] for i in keep}
+
+    # ---- G12: the reference's own inversion loops (inversion_tools/ddim_inversion.py:71-167): ddim_loop and
+    #      ddim_loop_plus (Easy-Inv averaging for 2.5 < i < 12.5, applied AFTER eps) through the stubs, tiny UNet,
+    #      single branch, with the up_blocks[2] feature dump at t=301 written by the reference's UNet forward
+    from inversion_tools.ddim_inversion import ddim_inversion as ref_ddim_inversion
+    F_, h_, w_ = 4, 16, 16
+    z0 = 0.7 * si.content_latent(0, F_, h_, w_)
+    keep_k = (1, 3, 4, 12, 13, 14, 50)
+    g12 = {}
+    for tag, is_opt in (("ddim_loop", False), ("ddim_loop_plus", True)):
+        unet = build_reference_unet(cfg, sd)
+        pipe = SpatioTemporalStableDiffusionPipeline(vae=FakeVAE(), text_encoder=FakeTextEncoder(text),
+                                                     tokenizer=FakeTokenizer(), unet=unet, scheduler=DDIMScheduler())
+        sch = DDIMScheduler()
+        sch.set_timesteps(50)
+        with tempfile.TemporaryDirectory() as td:
+            traj = ref_ddim_inversion(pipe, sch, z0, 50, "", td, ft_indices=[2], ft_timesteps=[301], ft_path=td, is_opt=is_opt)
+            files = [torch.load(os.path.join(td, f"ddim_latents_{k}.pt")) for k in range(51)]
+            feat = torch.load(os.path.join(td, "inversion_feature_map_2_block_301_step.pt"))
+        assert len(traj) == 51 and all(torch.equal(a, b) for a, b in zip(traj, files))
+        osch = pipeline_ref.DDIMSchedule()
+        osch.set_timesteps(50)
+        dump = {}
+
+        def eps_fn(z, t, i):
+            e, f = unet_ref.unet_forward(sd, cfg, z, int(t), text, None, ft_indices=[2] if int(t) == 301 else None,
+                                         exact_temporal=False)
+            if f:
+                dump["feat"] = f[2]
+            return e
+        mine = pipeline_ref.ddim_inversion_loop(eps_fn, osch, z0, 50, is_opt)
+        for k in keep_k:
+            chk(f"{tag}_k{k}", traj[k], mine[k], 2e-3)
+        chk(f"{tag}_feature_dump", feat, dump["feat"], 2e-3)
+        g12[tag] = {f"k{k}": traj[k].clone() for k in keep_k}
+        g12[tag]["feat"] = feat.clone()
+    assert not torch.equal(g12["ddim_loop"]["k4"], g12["ddim_loop_plus"]["k4"]) and \
+        torch.equal(g12["ddim_loop"]["k3"], g12["ddim_loop_plus"]["k3"]), "Easy-Inv window must start at i = 3"
+    gold["g12_inversion"] = g12
 
     for k, v in gold.items():
         torch.save(v, os.path.join(OUT, k + ".pt"))

@@ -1,0 +1,175 @@
+"""Parity at the BASELINE size (SD-v1.5 widths, F = 16 frames, 64x64 latents = 16x512x512, three branches, 50 DDIM steps):
+north_star's own acceptance numbers — output PSNR >= 40 dB vs the reference path, mask indices bit-exact.
+
+The oracle (oracle/unet_ref + oracle/pipeline_ref, pinned to the reference's modules by tests/golden) is evaluated in
+fp32 with torch ops ON THE DEVICE with the same fp16-valued weights (the CPU would need ~2 h for the 50 steps); the
+native path goes through the pipeline mirror -> engine -> one C-ABI call per UNet step.  Reference lines followed:
+backbones/video_diffusion_sd/pipelines/stable_diffusion.py:680-766, src/mask_propagation.py:15-99.
+
+Every test writes the numbers it measured to gpurun_out/parity_baseline_size.json (copied into DESIGN.md / BASELINE.md).
+"""
+import json
+import math
+import os
+import time
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet_ref, pipeline_ref, maskprop_ref, synth_inputs as si  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEEP = (0, 25, 26, 40, 41, 45, 46, 49)
+
+
+def record(key, value):
+    path = os.path.join(ROOT, "gpurun_out", "parity_baseline_size.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            data = json.load(f)
+    data[key] = value
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+def errs(got, ref):
+    got, ref = got.float(), ref.float().to(got.device)
+    e = got - ref
+    return e.abs().max().item() / ref.abs().max().item(), (e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+def psnr(got, ref):
+    got, ref = got.float(), ref.float().to(got.device)
+    mse = (got - ref).pow(2).mean().item()
+    peak = (ref.max() - ref.min()).item()
+    return 10 * math.log10(peak * peak / mse)
+
+
+@pytest.fixture(scope="module")
+def sd15():
+    """the synthetic SD-v1.5-shaped UNet (1.06 B parameters) + its weights as fp32 tensors for the oracle (same values)."""
+    from univst_amd import synth
+    unet = synth.build_unet(device="cuda", seed=7)
+    sd = {k: v.float() for k, v in unet.state_dict().items()}
+    unet_ref.SDPA_MAX_BATCH = 4            # fp32 math SDPA: 4*8*4096*12288*4 B = 6.4 GB of scores per call at most
+    yield unet, sd
+    unet_ref.SDPA_MAX_BATCH = None
+
+
+class _Tok:
+    model_max_length = 77
+
+    def __call__(self, prompt, **kw):
+        n = len(prompt) if isinstance(prompt, list) else 1
+        return types.SimpleNamespace(input_ids=torch.zeros(n, 77, dtype=torch.long), attention_mask=None)
+
+
+def _enc(text):
+    class Enc(torch.nn.Module):
+        config = types.SimpleNamespace()
+
+        def forward(self, ids, attention_mask=None):
+            return (text.half().cuda().expand(ids.shape[0], -1, -1),)
+    return Enc()
+
+
+def test_f16_forward_inside_and_outside_pnp_window(sd15):
+    """one three-branch forward at F = 16 (48 frames x 4096 tokens: the big-tile GEMM / tap-inner conv / d=40 pipelined
+    attention dispatches the headline bench runs, 16 distinct key-source frames) inside (idx 12) and outside (idx 40)
+    the PnP window.  Tolerance: max err <= 5e-3 * max|ref|, relative RMS <= 3e-3 over 22 ResBlocks + 16 transformer
+    blocks of fp16 storage (measured on MI355X: 1.6e-3 / 1.6e-3; the F = 2 test keeps the looser round-1 bound)."""
+    from univst_amd.backbones.video_diffusion_sd import pnp_utils
+    unet, sd = sd15
+    cfg = unet_ref.SD15_CONFIG
+    F_ = 16
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 4, F_, 64, 64, generator=g).half().cuda()
+    ctx = torch.randn(1, 77, 768, generator=g).half().cuda().expand(3, -1, -1).contiguous()
+    pipe = types.SimpleNamespace(unet=unet)
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    out = {}
+    for idx, t in ((12, 741), (40, 181)):
+        pnp_utils.register_time(pipe, idx)
+        got = unet(x, t, encoder_hidden_states=ctx).sample
+        with torch.no_grad():
+            ref, _ = unet_ref.unet_forward(sd, cfg, x.float(), t, ctx.float(), pnp_idx=idx, exact_temporal=False)
+        mx, rms = errs(got, ref)
+        out[f"idx{idx}"] = dict(max_rel=mx, rms_rel=rms)
+        assert torch.isfinite(got.float()).all()
+        assert mx < 5e-3 and rms < 3e-3, (idx, mx, rms)
+    record("f16_forward", out)
+
+
+@pytest.mark.parametrize("tag", ["mask", "nomask"])
+def test_f16_fifty_step_transfer_vs_oracle_on_device(sd15, tag):
+    """BASELINE config 3 without the optional smoother: the 50-step three-branch localized transfer at 16x512x512 with
+    moving-disc masks, native pipeline vs the oracle loop (fp32, device), same synthetic inversion trajectories.
+    PSNR of the stylised latents >= 40 dB at i in {0,25,26,40,41,45,46,49} (every branch of the step logic)."""
+    from univst_amd.backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
+    from univst_amd.backbones.video_diffusion_sd import pnp_utils
+    from univst_amd.schedulers import DDIMScheduler
+    unet, sd = sd15
+    cfg = unet_ref.SD15_CONFIG
+    F_, h, w, n = 16, 64, 64, 50
+    text = si.text_embedding(768)
+    pipe = SpatioTemporalStableDiffusionPipeline(vae=None, text_encoder=_enc(text), tokenizer=_Tok(), unet=unet, scheduler=DDIMScheduler())
+    ci = [si.content_latent(k, F_, h, w).half() for k in range(n + 1)]
+    sy = [si.style_latent(k, F_, h, w).half() for k in range(n + 1)]
+    masks = torch.from_numpy(pipeline_ref.mask_from_png_values(si.disc_masks(F_, 512, 512)))[None] if tag == "mask" else None
+    lat0 = pnp_utils.latent_adain(ci[n].cuda(), sy[n].cuda())
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    got = {}
+    t0 = time.time()
+    out = pipe.video_style_transfer("", latents=lat0, num_inference_steps=n, content_inv_latents=ci, style_inv_latents=sy,
+                                    masks=masks, output_type="latent",
+                                    callback=lambda i, t, l: got.__setitem__(i, l.clone()) if i in KEEP else None).images
+    torch.cuda.synchronize()
+    t_native = time.time() - t0
+    ctx = text.half().float().cuda().expand(3, -1, -1).contiguous()
+    cif = [t.float().cuda() for t in ci]
+    syf = [t.float().cuda() for t in sy]
+    ref = {}
+    t0 = time.time()
+    with torch.no_grad():
+        pipeline_ref.video_style_transfer_loop(
+            lambda x, t, i: unet_ref.unet_forward(sd, cfg, x, int(t), ctx, pnp_idx=i, exact_temporal=False)[0],
+            pipeline_ref.DDIMSchedule(), unet_ref.latent_adain(cif[n], syf[n]), cif, syf,
+            masks.cuda() if masks is not None else None, n,
+            callback=lambda i, t, l: ref.__setitem__(i, l.clone()) if i in KEEP else None)
+    torch.cuda.synchronize()
+    t_oracle = time.time() - t0
+    vals = {f"i{i}": psnr(got[i], ref[i]) for i in KEEP}
+    record(f"transfer50_{tag}", dict(psnr_db=vals, native_s=t_native, oracle_fp32_device_s=t_oracle))
+    assert torch.equal(out, got[49])
+    for i in KEEP:
+        assert torch.isfinite(got[i].float()).all() and vals[f"i{i}"] >= 40.0, vals
+
+
+def test_mask_propagation_bit_exact_full_size():
+    """mask indices bit-exact at the BASELINE size: 16 x 64x64 x 640 features (the up_blocks[2] dump), a multi-valued
+    anti-aliased 512^2 first mask (256 one-hot classes), 512^2 outputs — native kernels vs oracle/maskprop_ref on the CPU,
+    same torch.manual_seed(33) randperm stream (src/mask_propagation.py:15-99)."""
+    from univst_amd.src import mask_propagation as mp
+    feats = si.maskprop_features(F=16, h=64, w=64, C=640, seed=11)
+    first = si.soft_first_mask(512, 512)
+    assert int(np.array(first).max()) == 255 and len(np.unique(first)) > 100
+    args = mp.build_parser().parse_args([])
+    torch.manual_seed(33)
+    t0 = time.time()
+    got = np.stack(mp.propagate_masks(feats, first, args))
+    t_native = time.time() - t0
+    torch.manual_seed(33)
+    t0 = time.time()
+    ref = np.stack(maskprop_ref.video_mask_propagation(feats, first))
+    t_oracle = time.time() - t0
+    diff = [int((a != b).sum()) for a, b in zip(got, ref)]
+    record("maskprop_full", dict(mismatching_pixels_per_frame=diff, native_s=t_native, oracle_cpu_s=t_oracle,
+                                 foreground_px_last=int((ref[-1] != 0).sum())))
+    assert got.shape == ref.shape == (16, 512, 512) and got.dtype == np.uint8
+    assert sum(diff) == 0, diff

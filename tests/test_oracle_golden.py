@@ -147,3 +147,28 @@ def test_sd2_shaped_unet(golden):
     g = golden("g11_sd2")
     assert rel(unet_ref.unet_forward(sd, cfg, x[:1], 301, ctx[:1], None)[0], g["single"]) < TOL
     assert rel(unet_ref.unet_forward(sd, cfg, x, 781, ctx, pnp_idx=10)[0], g["pnp10"]) < TOL
+
+
+@pytest.mark.parametrize("tag,easy", [("ddim_loop", False), ("ddim_loop_plus", True)])
+def test_inversion_loops(golden, tag, easy):
+    """G12: the reference's own ddim_loop / ddim_loop_plus (inversion_tools/ddim_inversion.py:87-167; Easy-Inv averaging
+    for i = 3..12 applied after eps) and the t=301 feature dump of its UNet forward vs the oracle loop."""
+    g = golden("g12_inversion")[tag]
+    cfg = unet_ref.TINY_CONFIG
+    sd = unet_ref.synth_state_dict(cfg, seed=33)
+    text = si.text_embedding(cfg["cross_attention_dim"])
+    z0 = 0.7 * si.content_latent(0, 4, 16, 16)
+    osch = pipeline_ref.DDIMSchedule()
+    osch.set_timesteps(50)
+    dump = {}
+
+    def eps_fn(z, t, i):
+        e, f = unet_ref.unet_forward(sd, cfg, z, int(t), text, None, ft_indices=[2] if int(t) == 301 else None, exact_temporal=False)
+        if f:
+            dump["feat"] = f[2]
+        return e
+    with torch.no_grad():
+        mine = pipeline_ref.ddim_inversion_loop(eps_fn, osch, z0, 50, easy)
+    for k in (1, 3, 4, 12, 13, 14, 50):
+        assert rel(mine[k], g[f"k{k}"]) < TOL, k
+    assert rel(dump["feat"], g["feat"]) < TOL
