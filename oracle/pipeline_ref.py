@@ -117,3 +117,38 @@ def video_style_transfer_loop(unet_fn: Callable, sched: DDIMSchedule, latents: t
         if callback is not None:
             callback(i, t, latents)
     return latents
+
+
+def get_images_from_latents(vae_decode: Callable, latents: torch.Tensor) -> np.ndarray:
+    """stable_diffusion.py:793-819: 1/0.18215 * z -> VAE decode -> (x/2+0.5).clamp(0,1) -> (x*255).round() uint8,
+    [b,3,F,H,W] numpy.  ``vae_decode(z[(b f),4,h,w]) -> [(b f),3,H,W]``."""
+    b, c, f, h, w = latents.shape
+    z = (1 / 0.18215 * latents).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    x = (vae_decode(z) / 2 + 0.5).clamp(0, 1)
+    x = (x.cpu().float().numpy() * 255).round().astype("uint8")
+    return x.reshape(b, f, *x.shape[1:]).transpose(0, 2, 1, 3, 4)
+
+
+def get_latent_image(vae_encode: Callable, frames_u8: np.ndarray, dtype=torch.float32) -> torch.Tensor:
+    """stable_diffusion.py:821-834: frames/127.5 - 1 -> VAE encode (latent_dist.sample()) -> 0.18215 * z, [b,4,F,h,w]."""
+    b, c, f, H, W = frames_u8.shape
+    x = torch.from_numpy((frames_u8.transpose(0, 2, 1, 3, 4).reshape(b * f, c, H, W) / 127.5) - 1.0).to(dtype)
+    z = vae_encode(x)
+    return 0.18215 * z.reshape(b, f, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+
+
+def pixel_smoother(sched: DDIMSchedule, vae_decode: Callable, vae_encode: Callable, flow_fn: Callable,
+                   mask01: np.ndarray) -> Callable:
+    """the `smoother == 'pixel'` block of stable_diffusion.py:713-759 as the ``smoother(i, t, latents, eps)`` callable of
+    video_style_transfer_loop: x0 from the scheduler step (:718), decode to uint8 frames, sliding-window smoothing
+    (flow_ref.sliding_window_smooth = :723-751 incl. the masked restore), re-encode, and the noise that returns to
+    timestep t (:782-791).  mask01: uint8 {0,1} [1,F,H,W] (load_mask output)."""
+    from . import flow_ref
+
+    def fn(i, t, latents, eps):
+        _, x0 = sched.step(eps, t, latents)
+        frames = get_images_from_latents(vae_decode, x0)
+        frames = flow_ref.sliding_window_smooth(frames, flow_fn, mask01)
+        x0s = get_latent_image(vae_encode, frames, latents.dtype).to(latents.device)
+        return sched.return_to_timestep(t, latents, x0s)
+    return fn

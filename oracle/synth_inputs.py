@@ -68,3 +68,58 @@ def translation_flow(H: int, W: int, dx: float, dy: float, seed: int, noise=0.25
     f[..., 0] = dx
     f[..., 1] = dy
     return f + (noise * g.randn(H, W, 2)).astype(np.float32)
+
+
+class FakeLinearVAE(torch.nn.Module):
+    """Deterministic stand-in for the SVD temporal VAE in smoothing-leg tests (no VAE weights exist on either box):
+    decode = fixed 1x1 channel mix 4 -> 3*64 + pixel_shuffle(8), encode = pixel_unshuffle(8) + its pseudo-inverse, so
+    encode(decode(z)) == z up to rounding.  Duck-types what the pipeline touches: ``.config.scaling_factor``,
+    ``.config.block_out_channels`` (len 4 => x8), ``decode(z, num_frames=).sample``, ``encode(x).latent_dist.sample()``."""
+
+    def __init__(self, seed=21):
+        super().__init__()
+        import types
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        wd = 0.35 * torch.randn(192, 4, generator=g)
+        self.wd = torch.nn.Parameter(wd, requires_grad=False)
+        self.we = torch.nn.Parameter(torch.linalg.pinv(wd.double()).float(), requires_grad=False)
+        self.config = types.SimpleNamespace(scaling_factor=0.18215, block_out_channels=(1, 1, 1, 1))
+
+    def forward(self, x, num_frames=1):
+        return x
+
+    def decode_tensor(self, z):
+        y = torch.nn.functional.conv2d(z, self.wd.to(z.dtype)[:, :, None, None])
+        return torch.nn.functional.pixel_shuffle(y, 8)
+
+    def encode_tensor(self, x):
+        y = torch.nn.functional.pixel_unshuffle(x, 8)
+        return torch.nn.functional.conv2d(y, self.we.to(x.dtype)[:, :, None, None])
+
+    def decode(self, z, num_frames=1):
+        import types
+        return types.SimpleNamespace(sample=self.decode_tensor(z))
+
+    def encode(self, x):
+        import types
+        z = self.encode_tensor(x)
+        return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: z, mode=lambda: z))
+
+
+class CountingFlow:
+    """RAFT stand-in for the smoothing-leg tests: the k-th call returns a seeded analytic translation field (+ noise, + a
+    patch that trips the occlusion test) that depends only on k — native and oracle loops ask in the same order
+    (key frame ascending, neighbour ascending, forward then backward: stable_diffusion.py:731-747, cal_optica_flow.py:78-79)."""
+
+    def __init__(self, H, W):
+        self.H, self.W, self.k = H, W, 0
+
+    def __call__(self, a=None, b=None):
+        k = self.k
+        self.k += 1
+        sgn = 1.0 if k % 2 == 0 else -1.0
+        d = 1.0 + (k // 2) % 3
+        f = translation_flow(self.H, self.W, sgn * 1.3 * d, -sgn * 0.7 * d, 500 + k, noise=0.2)
+        if k % 2 == 1:
+            f[self.H // 8:self.H // 4, self.W // 4:self.W // 2] += 3.0
+        return f

@@ -172,3 +172,60 @@ def test_inversion_loops(golden, tag, easy):
     for k in (1, 3, 4, 12, 13, 14, 50):
         assert rel(mine[k], g[f"k{k}"]) < TOL, k
     assert rel(dump["feat"], g["feat"]) < TOL
+
+
+def test_get_warp_composition(golden):
+    """G13: the reference's get_warp (cal_optica_flow.py:51-99) with RAFT replaced by seeded flows and cv2.remap by the
+    restated fixed-point remap: which flow warps, the 1.5 px occlusion threshold, the composite over ref_image1."""
+    H = W = 96
+    f_fwd = si.translation_flow(H, W, 3.3, -2.7, 101, noise=0.6)
+    f_bwd = si.translation_flow(H, W, -3.3, 2.7, 102, noise=0.6)
+    f_bwd[5:15, 20:40] += 4.0
+    rs = np.random.RandomState(13)
+    im1, im2 = rs.randint(0, 256, (H, W, 3)).astype(np.uint8), rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    k = [0]
+
+    def flow_fn(a, b):
+        k[0] += 1
+        return (f_fwd, f_bwd)[(k[0] - 1) % 2]
+    assert np.array_equal(flow_ref.get_warp(flow_fn, im1, im2), golden("g13_get_warp")["warped"].numpy())
+
+
+def test_pixel_smoother_leg_of_the_loop():
+    """the smoothing leg (stable_diffusion.py:713-759) inside the oracle loop: active exactly for i in [20,25), changes the
+    trajectory from step 20 on, and asks for 2 flows per warp x 58 boundary-clipped warps per step."""
+    cfg = unet_ref.TINY_CONFIG
+    sd = unet_ref.synth_state_dict(cfg, seed=33)
+    F_, h_, w_ = 16, 8, 8
+    ctx = si.text_embedding(cfg["cross_attention_dim"]).expand(3, -1, -1).contiguous()
+    ci = [si.content_latent(k, F_, h_, w_) for k in range(51)]
+    sy = [si.style_latent(k, F_, h_, w_) for k in range(51)]
+    m01 = torch.from_numpy(pipeline_ref.mask_from_png_values(si.disc_masks(F_, h_ * 8, w_ * 8)))[None]
+    vae = si.FakeLinearVAE()
+    z = torch.randn(3, 4, h_, w_)
+    assert (vae.encode_tensor(vae.decode_tensor(z)) - z).abs().max() < 1e-4
+    calls = []
+
+    def run(with_smoother):
+        osch = pipeline_ref.DDIMSchedule()
+        osch.set_timesteps(50)
+        flow = si.CountingFlow(h_ * 8, w_ * 8)
+        sm = None
+        if with_smoother:
+            inner = pipeline_ref.pixel_smoother(osch, vae.decode_tensor, vae.encode_tensor, flow, m01.numpy())
+
+            def sm(i, t, lat, eps):
+                calls.append(i)
+                return inner(i, t, lat, eps)
+        got = {}
+        with torch.no_grad():
+            pipeline_ref.video_style_transfer_loop(
+                lambda x, t, i: unet_ref.unet_forward(sd, cfg, x, int(t), ctx, pnp_idx=i, exact_temporal=False)[0],
+                osch, unet_ref.latent_adain(ci[50], sy[50]), ci, sy, m01, 50, smoother=sm,
+                callback=lambda i, t, l: got.__setitem__(i, l.clone()))
+        return got, flow.k
+    a, _ = run(False)
+    b, nflow = run(True)
+    assert calls == [20, 21, 22, 23, 24]
+    assert nflow == 5 * 2 * 58                      # 16 key frames x up to 4 neighbours, boundary-clipped = 58 warps per step
+    assert all(torch.equal(a[i], b[i]) for i in range(20)) and not torch.allclose(a[20], b[20], atol=1e-3)
