@@ -10,6 +10,13 @@ on steps 41..45, all three branches computed on every step (reference-equivalent
 One "step" = one DDIM step of that loop (steps i = 0..K-1 of the 50-step schedule, wrapping modulo 50);
 value = F / (50 * mean step time) frames/s — with the default K = 50 that is exactly one full transfer.
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+The default workload is the headline (BASELINE config 3 without the optional smoother: localized transfer, moving-disc
+masks blended on steps 0..45).  --workload selects the other driver-timed lines (same JSON shape, own `roofline`):
+  transfer_nomask   the same loop without masks
+  inversion         BASELINE config 2: the single-branch DDIM inversion loop (one step = one single-branch UNet call + next_step)
+  maskprop          point-matching mask propagation of a 16-frame clip (64x64x640 features, 256 classes, 512^2 masks); HBM-bound
+  warp              one sliding-window smoothing pass over 16 x 512^2 frames (58 occlusion + remap + blend launches); HBM-bound
 """
 import argparse
 import json
@@ -37,6 +44,9 @@ def parse():
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
+    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "maskprop", "warp"])
+    ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
+                                                             "(no extrapolation in F; ~2 min on 16 threads) instead of F=2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-skip-dead-branches-leg", action="store_true",
@@ -83,11 +93,11 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(frames_full, unet=None):
+def cpu_baseline(frames_full, unet=None, full=False, single_branch=False):
     """oracle ('port' of the reference algorithm, fp32 PyTorch CPU ops, reference plumbing incl. the dead temporal
-    ops) on this box's host cores: TWO three-branch UNet steps at F=2 of the 16 frames (one inside the PnP window, one
-    outside), extrapolated linearly in F (sparse-causal attention / convs / norms are all frame-linear) and to the
-    26 + 24 steps of the loop."""
+    ops) on this box's host cores: TWO UNet steps (one inside the PnP window, one outside) at F=2 of the clip's frames —
+    extrapolated linearly in F (sparse-causal attention / convs / norms are all frame-linear) — or, with --full-cpu, at
+    the full frame count; then weighted to the 26 + 24 steps of the loop.  single_branch: the inversion step (no PnP)."""
     from oracle import unet_ref, synth_inputs as si
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -97,21 +107,107 @@ def cpu_baseline(frames_full, unet=None):
         sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     else:
         sd = unet_ref.synth_state_dict(cfg, seed=33)
-    F_s = 2
-    x = torch.cat([si.content_latent(40, F_s, 64, 64), si.style_latent(40, F_s, 64, 64), si.content_latent(39, F_s, 64, 64)])
-    ctx = si.text_embedding(768).expand(3, -1, -1).contiguous()
+    F_s = frames_full if full else 2
+    if single_branch:
+        x = si.content_latent(40, F_s, 64, 64)
+        ctx = si.text_embedding(768)
+    else:
+        x = torch.cat([si.content_latent(40, F_s, 64, 64), si.style_latent(40, F_s, 64, 64), si.content_latent(39, F_s, 64, 64)])
+        ctx = si.text_embedding(768).expand(3, -1, -1).contiguous()
     t1 = time.time()
     with torch.no_grad():
-        unet_ref.unet_forward(sd, cfg, x, 781, ctx, pnp_idx=10, exact_temporal=True)     # a step inside the PnP window (i <= 25)
+        unet_ref.unet_forward(sd, cfg, x, 781, ctx, pnp_idx=None if single_branch else 10, exact_temporal=True)   # inside the PnP window
         t2 = time.time()
-        unet_ref.unet_forward(sd, cfg, x, 381, ctx, pnp_idx=30, exact_temporal=True)     # a step outside it
-    t_in, t_out = t2 - t1, time.time() - t2
+        if single_branch:
+            t_in, t_out = t2 - t1, t2 - t1
+        else:
+            unet_ref.unet_forward(sd, cfg, x, 381, ctx, pnp_idx=30, exact_temporal=True)     # a step outside it
+            t_in, t_out = t2 - t1, time.time() - t2
     # the 50-step loop has 26 steps inside the window (i = 0..25) and 24 outside; per-step cost has no other data dependence
     loop_full = (26 * t_in + 24 * t_out) * frames_full / F_s
-    return dict(value=frames_full / loop_full, unit="frames/s", cores=cores, kind="port",
-                sample=f"2 three-branch UNet steps (one inside the PnP window: {t_in:.1f} s, one outside: {t_out:.1f} s; fp32, all "
-                       f"temporal ops) at F={F_s} of {frames_full} frames, 64x64 latents, on {cores} threads (cgroup quota); extrapolated "
-                       f"x{frames_full // F_s} in F and to 26 + 24 steps (weight copy {t1 - t0:.0f} s excluded)")
+    what = "single-branch UNet step (inversion)" if single_branch else "three-branch UNet steps (one inside the PnP window, one outside)"
+    return dict(value=frames_full / loop_full, unit="frames/s", cores=cores, kind="port", extrapolated=not full,
+                sample=f"{1 if single_branch else 2} {what}: {t_in:.1f} s / {t_out:.1f} s; fp32, all temporal ops, at F={F_s} of "
+                       f"{frames_full} frames, 64x64 latents, on {cores} threads (cgroup quota); "
+                       + ("" if full else f"EXTRAPOLATED x{frames_full // F_s} in F and ") + f"weighted to 26 + 24 steps (weight copy {t1 - t0:.0f} s excluded)")
+
+
+def hbm_roofline(kernel, algorithmic_bytes, ms, launches):
+    gbs = algorithmic_bytes / (ms * 1e-3) / 1e9
+    return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(ms / launches, 4),
+            "algorithmic_mb_per_launch": round(algorithmic_bytes / launches / 1e6, 2)}
+
+
+def run_aux_workload(a, dev):
+    """the two HBM-bound producers / post-processors of the path as driver-timed lines (SURVEY §8d byte counts)."""
+    from univst_amd.src import mask_propagation as mp, cal_optica_flow as cf
+    from oracle import synth_inputs as si            # seeded synthetic inputs only (no oracle compute in the timed region)
+    import numpy as np
+    F_ = a.frames
+    out_cfg = {"frames": F_, "parallelism": "single"}
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.workload == "maskprop":
+        feats = si.maskprop_features(F=F_, h=64, w=64, C=640, seed=11).to(dev)
+        first = si.soft_first_mask(512, 512)
+        args = mp.build_parser().parse_args([])
+        args.num_frames = F_
+
+        def once():
+            torch.manual_seed(33)
+            return mp.propagate_masks(feats, first, args)
+        unit_desc = "propagated masks"
+        units = F_ - 1
+        # per frame: affinity matrix [Nsrc<=~13.7k, 4096] fp32 written once + read 3x (top-k threshold, normalise, label GEMM)
+        # + the [256, 512, 512] fp32 upsample field is never materialised (fused finalize): ~0.9 GB at the full queue (SURVEY §8d)
+        alg_bytes = None
+    else:
+        H = W = 512
+        rs = np.random.RandomState(3)
+        frames = torch.from_numpy(rs.randint(0, 256, (1, 3, F_, H, W)).astype(np.uint8)).to(dev)
+        mask = torch.from_numpy((rs.rand(F_, H, W) > 0.7).astype(np.uint8)).to(dev)
+        flows = [torch.from_numpy(si.translation_flow(H, W, 3.3 * ((k % 3) - 1), -2.7 * ((k % 2) * 2 - 1), 100 + k, noise=0.6)).to(dev)
+                 for k in range(8)]
+        cnt = [0]
+
+        def flow_fn(x, y):
+            cnt[0] += 1
+            return flows[cnt[0] % 8]
+
+        def once():
+            return cf.sliding_window_smooth(frames, flow_fn, mask)
+        unit_desc = "smoothed frames"
+        units = F_
+        nwarp = sum(1 for k in range(F_) for b in (-2, -1, 1, 2) if 0 <= k + b < F_)
+        alg_bytes = nwarp * H * W * 25.0          # 3 src + 3 key + 8 fwd + 8 bwd + 3 out bytes per pixel and warp (SURVEY §8d)
+    for _ in range(max(1, a.warmup)):
+        once()
+    torch.cuda.synchronize()
+    reps = max(1, a.steps // 10)
+    ev0.record()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    dev_ms = ev0.elapsed_time(ev1) / reps
+    out = {"metric": f"{unit_desc}/sec, {F_}-frame clip at 512x512 ({a.workload})", "value": round(units / wall, 3), "unit": "frames/s",
+           "n_gpus": 1, "steps": reps, "warmup": max(1, a.warmup), "ms_per_step": round(wall * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.workload == "maskprop" else "u8", "data": "synthetic",
+           "config": dict(out_cfg, workload=("maskprop_16x64x64x640_256cls_512sq" if a.workload == "maskprop" else "sliding_window_warp_blend_16x512x512_r2"))}
+    if a.workload == "warp":
+        out["roofline"] = hbm_roofline("warp_accumulate_kernel (occlusion test + fixed-point remap + blend, 58 launches) + window_store",
+                                       alg_bytes, dev_ms, nwarp)
+        out["roofline"]["note"] = "launch-latency bound at 512^2 (6.6 MB per warp): the host loop is sequential over key frames like the reference"
+    else:
+        # traffic model per frame: |aff| = Nsrc x 4096 fp32, 1 write + 3 reads; Nsrc grows 4096 -> ~13.7k as the queue fills
+        nsrc = [4096 + min(k, 9) * 1070 for k in range(F_ - 1)]
+        alg_bytes = sum(n * 4096 * 4 * 4.0 for n in nsrc)
+        out["roofline"] = hbm_roofline("maskprop_frame (row-normalise, affinity SGEMM + exp, top-15 threshold, column normalise, label SGEMM) + finalize",
+                                       alg_bytes, dev_ms, F_ - 1)
+        out["roofline"]["note"] = "host randperm sub-sampling between frames (reference RNG stream) is inside the timed region"
+    return out
 
 
 def main():
@@ -133,6 +229,14 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local)
 
+    if a.workload in ("maskprop", "warp"):
+        assert world == 1, "maskprop / warp are sequential over frames: replicas only (DESIGN.md §5)"
+        from univst_amd import _native
+        _native.load()
+        out = run_aux_workload(a, dev)
+        print(json.dumps(out))
+        return
+
     from univst_amd import _native, synth
     from univst_amd.backbones.video_diffusion_sd import pnp_utils
     from univst_amd.schedulers import DDIMScheduler
@@ -150,14 +254,33 @@ def main():
     unet = synth.build_unet(device=dev, seed=33)
     pipe = Pipe(unet, DDIMScheduler())
     pipe.scheduler.set_timesteps(50)
-    pnp_utils.register_spatial_attention_pnp(pipe)
-    content, style, text3, _ = synth.synth_transfer_inputs(F=F_total, h=h, w=h, device=dev)
+    if a.workload != "inversion":          # the inversion UNet is the stock one (run_content_inversion_sd.py never registers PnP)
+        pnp_utils.register_spatial_attention_pnp(pipe)
+    masked = a.workload == "transfer"
+    content, style, text3, mask = synth.synth_transfer_inputs(F=F_total, h=h, w=h, device=dev, with_mask=masked, mask_hw=8 * h)
     content = [shard.slice_frames(t) for t in content]
     style = [shard.slice_frames(t) for t in style]
-    shard.attach(unet)
+    mask_m = None
+    if masked:          # load_mask() output {0,1} [1,F,512,512] -> bilinear /8 once (stable_diffusion.py:688-691), this rank's frames
+        mask_m = _native.mask_resize(mask.reshape(-1, 8 * h, 8 * h).contiguous(), h, h)
+        mask_m = mask_m.reshape(-1, h, h)[shard.f0:shard.f0 + shard.local].contiguous()
+    shard.attach(unet, max_tokens=h * h)
     sharded = world > 1 or emu is not None
-    lat = shard.latent_adain(content[50], style[50]) if sharded else pnp_utils.latent_adain(content[50], style[50])
-    step = shard.make_step_fn(pipe, content, style, text3) if sharded else make_step_fn(pipe, content, style, text3, None)
+    if a.workload == "inversion":
+        from univst_amd import engine
+        assert not sharded, "--workload inversion: single GPU line (config 2)"
+        pipe.unet = unet
+        text1 = text3[2:3].contiguous()
+        ts = [int(t) for t in pipe.scheduler.timesteps.tolist()]
+        lat = content[0]
+
+        def step(i, z):
+            t = ts[len(ts) - (i % 50) - 1]
+            eps = unet(z, t, encoder_hidden_states=text1).sample
+            return engine.next_step(eps, t, z, pipe.scheduler)
+    else:
+        lat = shard.latent_adain(content[50], style[50]) if sharded else pnp_utils.latent_adain(content[50], style[50])
+        step = shard.make_step_fn(pipe, content, style, text3, mask_m) if sharded else make_step_fn(pipe, content, style, text3, mask_m)
 
     def sync():
         torch.cuda.synchronize()
@@ -182,11 +305,14 @@ def main():
     value = F_total / (50 * ms_per_step / 1e3)
 
     out = {
-        "metric": "stylized frames/sec, SD-v1.5 16x512x512 @50 DDIM steps", "value": round(value, 4), "unit": "frames/s",
+        "metric": ("inverted frames/sec, SD-v1.5 16x512x512 @50 DDIM inversion steps" if a.workload == "inversion" else
+                   "stylized frames/sec, SD-v1.5 16x512x512 @50 DDIM steps"), "value": round(value, 4), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"sd15_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim", "frames": F_total,
-                   "latent": [1, 4, F_total, h, h], "branches": 3, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
+        "config": {"workload": (f"sd15_unet_single_branch_ddim_inversion_{F_total}x{h * 8}x{h * 8}_50ddim" if a.workload == "inversion" else
+                                f"sd15_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
+                   "latent": [1, 4, F_total, h, h], "branches": 1 if a.workload == "inversion" else 3,
+                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
                    "weights": "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16"},
     }
 
@@ -219,25 +345,36 @@ def main():
                            "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2),
                            "classes": classes}
         # HBM traffic per launch of that kernel from the committed PMC passes (bench.py cannot collect PMCs itself):
-        # profiles/round1_pmc_traffic.json = rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this command
+        # profiles/roundN_pmc_traffic.json = rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this command
+        # (tools/refresh_profiles.sh; re-collected whenever the kernel changes — the newest round's file wins)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")))["kernels"]
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("round") and f.endswith("_pmc_traffic.json"))
+            pm = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["kernels"]
             key = dom.replace(" ", "")
             hit = [v for k, v in pm.items() if key.split("<")[0] in k and key.split("<")[1].rstrip(">") in k.replace(" ", "")]
             if hit and world == 1:
                 out["roofline"]["traffic"] = hit[0]["hbm_bytes_per_launch_corrected"]
-                out["roofline"]["traffic_source"] = "profiles/round1_pmc_traffic.json (rocprofv3 PMC, gfx950-corrected, bytes/launch)"
+                out["roofline"]["traffic_source"] = f"profiles/{cands[-1]} (rocprofv3 PMC, gfx950-corrected, bytes/launch)"
         except Exception:
             pass
+        if a.workload != "inversion":
+            Fl = shard.local
+            # duplicate key sources are merged exactly (frame 0: {0,0,0} -> one read with log2(3) added; frame 1: {0,1,0} / {0,0}):
+            # executed attention work / algorithmic work, stock and PnP layers, for this rank's frames
+            f0 = shard.f0
+            stock = sum(len({max(f - 1, 0), f, 0}) for f in range(f0, f0 + Fl)) / (3.0 * Fl)
+            pnp_l = sum(len({max(f - 1, 0), 0}) for f in range(f0, f0 + Fl)) / (2.0 * Fl)
+            out["roofline"]["attn_executed_over_algorithmic"] = {"stock_layers": round(stock, 4), "pnp_layers": round(pnp_l, 4),
+                                                                 "note": "TFLOP/s figures use the ALGORITHMIC flops (reference key multiplicities)"}
         tot_flops = sum(v["flops"] for v in prof.values()) / nprof
         out["config"]["algorithmic_tflop_per_step_executed"] = round(tot_flops / 1e12, 2)
         out["roofline"]["whole_step_tflops"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12, 1)
 
-    if not a.no_skip_dead_branches_leg and world == 1 and emu is None and a.steps >= 50:
+    if not a.no_skip_dead_branches_leg and world == 1 and emu is None and a.steps >= 50 and a.workload != "inversion":
         from univst_amd import engine
         sync()
         t0 = time.perf_counter()
-        engine.transfer_loop(pipe, pnp_utils.latent_adain(content[50], style[50]), text3, content, style, None, 50,
+        engine.transfer_loop(pipe, pnp_utils.latent_adain(content[50], style[50]), text3, content, style, mask if masked else None, 50,
                              skip_dead_branches=True)
         sync()
         out["config"]["extra_skip_dead_branches_frames_per_s"] = round(F_total / (time.perf_counter() - t0), 4)
@@ -246,7 +383,7 @@ def main():
 
     if rank == 0:
         if not a.no_cpu_baseline and world == 1 and emu is None:
-            out["cpu_baseline"] = cpu_baseline(F_total, unet)
+            out["cpu_baseline"] = cpu_baseline(F_total, unet, full=a.full_cpu, single_branch=a.workload == "inversion")
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -99,6 +99,14 @@ int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, i
 int univst_conv_nhwc_tapinner(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, int stride,
                               const void* W, const void* bias, const void* rowbias, int rows_per_rowbias,
                               const void* residual, void* Y, int Cout, void* stream);
+/* the 3x3 / stride-1 conv (optionally over the nearest x2 upsampled input) from an input patch kept in LDS
+ * (conv_patch_kernel): weight layout [Cout][(C1+C2)/32][9][32]
+ * (C1, C2 multiples of 32, Cout multiple of 320, image width a multiple of 16, whole image rows per 256/192-row tile, at
+ * least 150 tiles — otherwise UNIVST_ERR_ARG: the UNet graph passes both weight copies and falls back by itself).
+ * Replaces resnet.py:57-80 for the 64x64 .. 16x16 levels. */
+int univst_conv3x3_patch(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, const void* W32,
+                         const void* bias, const void* rowbias, int rows_per_rowbias, const void* residual, void* Y, int Cout,
+                         void* stream);
 /* GroupNorm(+SiLU) on NHWC rows; rows_per_stat = F*H*W (5-D, stats across frames: resnet.py:338,369) or H*W
  * (per frame: attention.py:121).  workspace: univst_groupnorm_workspace_bytes(). */
 int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups);

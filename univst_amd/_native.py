@@ -43,6 +43,7 @@ SIGNATURES = {
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "univst_conv3x3_patch": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_groupnorm_workspace_bytes": (_L, [_L, _I, _I]),
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
@@ -150,6 +151,20 @@ def conv_nhwc_tapinner(x1, w_ti, bias=None, x2=None, upsample=False, stride=1, r
     return out
 
 
+def conv3x3_patch(x1, w_t32, bias=None, x2=None, rowbias=None, rows_per_rowbias=1, residual=None, upsample=False):
+    """3x3 / stride-1 conv through the LDS-patch kernel, weight layout [Cout, Cin/32, 9, 32]; raises when the problem is
+    not eligible for that kernel (it never falls back silently)."""
+    _f16(x1), _f16(w_t32)
+    imgs, Hs, Ws, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[-1]
+    Cout = w_t32.shape[0]
+    He, We = (Hs * 2, Ws * 2) if upsample else (Hs, Ws)
+    out = torch.empty(imgs, He, We, Cout, device=x1.device, dtype=torch.float16)
+    check(load().univst_conv3x3_patch(ptr(x1), ptr(x2), C1, C2, imgs, Hs, Ws, int(upsample), ptr(w_t32), ptr(bias), ptr(rowbias), rows_per_rowbias,
+                                      ptr(residual), ptr(out), Cout, stream_ptr()), "conv3x3_patch")
+    return out
+
+
 def groupnorm_nhwc(x1, gamma, beta, groups, eps, rows_per_stat, silu=False, x2=None):
     _f16(x1)
     C1 = x1.shape[-1]
@@ -232,7 +247,8 @@ def debug_tr16():
 
 
 PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>", "gemm_kernel<*,1>", "attn_pp40_kernel<true>",
-                   "attn_kernel_occ3<96,5,2>", "attn_kernel<other>", "groupnorm", "layernorm", "adain_shift")
+                   "attn_kernel_occ3<96,5,2>", "attn_kernel<other>", "groupnorm", "layernorm", "adain_shift", "attn_kernel<text>",
+                   "conv_patch_kernel")
 
 
 def profile_enable(on: bool):

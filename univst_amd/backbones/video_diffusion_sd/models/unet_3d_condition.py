@@ -17,6 +17,7 @@ gfx950 kernels behind ``libunivst_hip.so`` (one C-ABI call per step); there is n
 import glob
 import json
 import os
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Tuple, Union
 
@@ -110,14 +111,17 @@ class SpatioTemporalTransformerBlock(_ParamOnly):
         self.norm3 = nn.LayerNorm(dim)
 
 
+# construction-time switch read by SpatioTemporalTransformerModel (thread-local: the loopback tests build one UNet per thread)
+_BUILD = threading.local()
+
+
 class SpatioTemporalTransformerModel(_ParamOnly):
     """attention.py:40-102 (ctor; 1x1-conv projections for SD-v1.x, Linear for SD-v2.x use_linear_projection)."""
-    use_linear_projection = False
 
     def __init__(self, heads, dim_head, in_channels, cross_attention_dim, groups):
         super().__init__()
         inner = heads * dim_head
-        lin = SpatioTemporalTransformerModel.use_linear_projection
+        lin = getattr(_BUILD, "use_linear_projection", False)      # set by the UNet constructor of THIS thread
         self.norm = nn.GroupNorm(num_groups=groups, num_channels=in_channels, eps=1e-6, affine=True)
         self.proj_in = nn.Linear(in_channels, inner) if lin else nn.Conv2d(in_channels, inner, kernel_size=1, stride=1, padding=0)
         self.transformer_blocks = nn.ModuleList([SpatioTemporalTransformerBlock(inner, heads, dim_head, cross_attention_dim)])
@@ -267,7 +271,7 @@ class UNetPseudo3DConditionModel(nn.Module):
         if len(hl) != 4:
             raise NotImplementedError("attention_head_dim must be an int or a 4-tuple")
         self._heads_per_level = hl
-        SpatioTemporalTransformerModel.use_linear_projection = bool(use_linear_projection)
+        _BUILD.use_linear_projection = bool(use_linear_projection)
         ted = boc[0] * 4
         self.sample_size = sample_size
         self.conv_in = PseudoConv3d(in_channels, boc[0], kernel_size=3, padding=(1, 1))
@@ -299,12 +303,13 @@ class UNetPseudo3DConditionModel(nn.Module):
             else:
                 blk = CrossAttnUpBlockPseudo3D(in_c, out_c, prev_c, ted, layers_per_block + 1, groups, eps, hl[len(boc) - 1 - i], xdim, not final)
             self.up_blocks.append(blk)
-        SpatioTemporalTransformerModel.use_linear_projection = False
+        _BUILD.use_linear_projection = False
         self.conv_norm_out = nn.GroupNorm(num_channels=boc[0], num_groups=groups, eps=eps)
         self.conv_act = nn.SiLU()
         self.conv_out = PseudoConv3d(boc[0], out_channels, kernel_size=3, padding=1)
         self._native_handle = None
         self._native_dirty = True
+        self._native_fp = None
 
     # ------------------------------------------------------------------ nn.Module plumbing
     @property
@@ -342,7 +347,8 @@ class UNetPseudo3DConditionModel(nn.Module):
         if self.device.type != "cuda":
             raise RuntimeError("UNetPseudo3DConditionModel.forward runs only on an AMD GPU: call .cuda() first "
                                "(univst_amd has no CPU path)")
-        if self._native_handle is not None and not self._native_dirty:
+        fp = self._weights_fingerprint()
+        if self._native_handle is not None and not self._native_dirty and fp == self._native_fp:
             return
         if self._native_handle is not None:
             lib.univst_unet_destroy(self._native_handle)
@@ -369,6 +375,20 @@ class UNetPseudo3DConditionModel(nn.Module):
         _native.check(lib.univst_unet_finalize(h, stream), "unet_finalize")
         self._native_handle = h
         self._native_dirty = False
+        self._native_fp = fp
+
+    def _weights_fingerprint(self):
+        """(storage address, in-place version counter) of every parameter / buffer: the native copy (incl. the derived fused
+        QKV, tap-inner conv and stacked time_emb_proj tensors) is rebuilt when any of them was edited in place
+        (``p.data.copy_``, LoRA merges, optimizer steps ...) or re-allocated, not only on ``_apply`` / ``load_state_dict``."""
+        acc = 0
+        for t in self.state_dict(keep_vars=True).values():
+            acc = (acc * 1000003 + t.data_ptr() + 7919 * t._version) & 0xFFFFFFFFFFFFFFFF
+        return acc
+
+    def invalidate_native(self):
+        """force a rebuild of the native weight copy at the next forward."""
+        self._native_dirty = True
 
     def _pnp_state(self):
         """read back what pnp_utils.register_spatial_attention_pnp / register_time poked into the modules."""
@@ -423,10 +443,15 @@ class UNetPseudo3DConditionModel(nn.Module):
                 hh, ww = (H >> 3) << s, (W >> 3) << s
                 feat = torch.empty(F_, hh, ww, boc[ft_index], device=x.device, dtype=torch.float16)
         pnp = self._pnp_state()
-        _native.check(lib.univst_unet_forward(self._native_handle, x.data_ptr(), t, txt.data_ptr(), B, F_, H, W, txt.shape[1],
-                                              C.byref(pnp) if pnp is not None else None, eps.data_ptr(),
-                                              feat.data_ptr() if feat is not None else None, ft_index,
-                                              _native.stream_ptr()), "unet_forward")
+        shard = getattr(self, "_frame_shard", None)
+        if shard is not None:
+            shard.ensure(self, H * W)      # comm hooks on the current handle, workspace sized for this latent
+        rc = lib.univst_unet_forward(self._native_handle, x.data_ptr(), t, txt.data_ptr(), B, F_, H, W, txt.shape[1],
+                                     C.byref(pnp) if pnp is not None else None, eps.data_ptr(),
+                                     feat.data_ptr() if feat is not None else None, ft_index, _native.stream_ptr())
+        if rc and shard is not None:
+            shard.raise_pending("unet_forward")
+        _native.check(rc, "unet_forward")
         if feat is not None:
             tt = int(t) if float(int(t)) == t else t
             save_path = os.path.join(ft_path, f"inversion_feature_map_{ft_index}_block_{tt}_step.pt")

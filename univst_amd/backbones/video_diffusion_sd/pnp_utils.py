@@ -39,12 +39,15 @@ def attention_adain(cnt_feat, sty_feat, ad=True):
     """pnp_utils.py:114-125 on [c, N, C] features (stand-alone form of the fused shift kernel with
     beta = 1, alpha = 0, gamma = 1: K2 <- AdaIN(K2, K1))."""
     c, N, C = cnt_feat.shape
-    z = torch.zeros_like(cnt_feat)
-    q = torch.cat([z, z, z])
-    kv = torch.cat([z, sty_feat, cnt_feat])
-    buf = _as_f16_cuda(torch.cat([q, kv, kv], dim=-1).reshape(3 * c * N, 3 * C))
-    _native.attention_adain_shift_(buf, c, N, C, 0.0, 1.0, 1.0)
-    return buf.view(3 * c, N, 3 * C)[2 * c:, :, C:2 * C].to(cnt_feat.dtype)
+    if not (cnt_feat.is_cuda and sty_feat.is_cuda):
+        raise RuntimeError("univst_amd AdaIN kernels run on the GPU only (no CPU path): move the tensor to cuda")
+    # the fused kernel works in place on a [3c*N, 3C] QKV buffer; only K of the style (rows c..2c) and of the stylised
+    # branch (rows 2c..3c) are read, so one zeroed buffer with those two slices filled is all it needs
+    buf = torch.zeros(3 * c, N, 3 * C, dtype=torch.float16, device=cnt_feat.device)
+    buf[c:2 * c, :, C:2 * C] = sty_feat
+    buf[2 * c:, :, C:2 * C] = cnt_feat
+    _native.attention_adain_shift_(buf.view(3 * c * N, 3 * C), c, N, C, 0.0, 1.0, 1.0)
+    return buf[2 * c:, :, C:2 * C].to(cnt_feat.dtype)
 
 
 def latent_adain(cnt_feat, sty_feat, ad=True):

@@ -120,6 +120,19 @@ int univst_conv_nhwc_tapinner(const void* X1, const void* X2, int C1, int C2, in
     g.R = H(R); g.ldr = Cout; g.Y = HM(Y); g.ldy = Cout;
     return uv_launch_gemm(g, 1, S(s));
 }
+int univst_conv3x3_patch(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, const void* W32,
+                         const void* bias, const void* rowbias, int rows_per_rb, const void* R, void* Y, int Cout, void* s) {
+    UV_REQUIRE(X1 && W32 && Y, "conv3x3_patch: null argument");
+    UV_REQUIRE((X2 != nullptr) == (C2 > 0), "conv3x3_patch: X2/C2 mismatch");
+    GemmParams g;
+    g.X = H(X1); g.X2 = H(X2); g.C1 = C1; g.C2 = C2; g.Hs = Hs; g.Ws = Ws; g.up = upsample ? 1 : 0; g.stride = 1; g.taps = 9;
+    g.Ho = Hs << g.up; g.Wo = Ws << g.up;
+    g.M = imgs * g.Ho * g.Wo; g.N = Cout; g.K = 9 * (C1 + C2);
+    g.W = nullptr; g.W32 = H(W32);
+    g.bias = H(bias); g.rowbias = H(rowbias); g.rows_per_rb = rows_per_rb > 0 ? rows_per_rb : 1;
+    g.R = H(R); g.ldr = Cout; g.Y = HM(Y); g.ldy = Cout;
+    return uv_launch_gemm(g, 1, S(s));
+}
 int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups) {
     if (rows_per_stat <= 0) return 0;
     return (int64_t)uv_groupnorm_workspace_floats((int)(rows / rows_per_stat), groups) * 4;

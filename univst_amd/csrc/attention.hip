@@ -793,7 +793,9 @@ int uv_launch_attention(const AttnParams& p, hipStream_t stream) {
     UV_REQUIRE(p.nsrc >= 1 && p.Nkv >= 1 && p.Nq >= 1, "attention: empty problem");
     UV_REQUIRE(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must be multiples of 8");
     const double nkv = (double)p.nsrc * p.Nkv;
-    uv_prof_begin(p.d == 40 ? UV_CLS_ATTN_D40 : (p.d == 80 ? UV_CLS_ATTN_D80 : UV_CLS_ATTN_OTHER), 4.0 * p.BF * p.heads * (double)p.Nq * nkv * p.d,
+    const int cls = (p.nsrc == 1 && p.Nkv <= 128) ? UV_CLS_ATTN_TEXT
+                    : (p.d == 40 && p.Nq >= 2048) ? UV_CLS_ATTN_D40 : (p.d == 80 ? UV_CLS_ATTN_D80 : UV_CLS_ATTN_OTHER);
+    uv_prof_begin(cls, 4.0 * p.BF * p.heads * (double)p.Nq * nkv * p.d,
                   2.0 * p.BF * p.heads * p.d * (2.0 * p.Nq + 2.0 * nkv), stream);
     int rc = attn_dispatch(p, stream);
     uv_prof_end(stream);

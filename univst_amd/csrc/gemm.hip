@@ -583,6 +583,160 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 }
 
 
+// ----------------------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 convolution (optionally over the nearest-x2 upsampled input) from an INPUT PATCH kept in LDS (the 64x64 ..
+// 16x16 levels: 19 of the step's 46.7 TFLOP).
+//
+// gemm_big_kernel<1> stages one im2col tile per k tile: every input pixel enters LDS nine times (once per tap), the
+// LDS-DMA lands at ~64 B/clk/CU, and its 72 KB per k tile next to 224 KB of fragment reads make the LDS port the
+// co-limiter of the tile.  Here the block's output tile is R whole image rows; for a 32-channel slab the
+// (R+2) x (W+2) input pixels those rows touch are DMA'd ONCE (25 KB at the 64x64 level) and the nine taps read their B
+// fragments from it at shifted pixel offsets — no per-tap im2col addressing, no padding masks (halo pixels are zero in
+// the patch), 37 % fewer LDS-DMA bytes.  Weights stream as before (320 x 64 k per barrier, two buffers); a k tile is two
+// consecutive (slab, tap) units of the k order [Cin/32][9][32] (GemmParams::W32), so one barrier still covers 80 MFMAs
+// per wave; patches sit in a two-slab ring and are refilled two slabs ahead.
+//
+// Patch image: pixel-major, 64 B per pixel (32 channels), 16-byte chunk c of pixel p stored at chunk c ^ (((p >> 2) & 1) << 1):
+// conflict-free for the ds_read_b128 lane groups at ANY pixel shift (brute-forced against MI355X_MICROARCH.md §LDS).
+// The swizzle is applied to the per-lane SOURCE address (the DMA writes lane-linear) and to the fragment reads.
+// A tile may straddle two images (192-row tiles do): one zero row is inserted between them, which serves as the bottom
+// padding of the upper image and the top padding of the lower one.
+template <int MJ>
+__global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
+    constexpr int NF = 10, BMB = 64 * MJ, BNB = 320, LDSH = 64;
+    constexpr int PROUNDS = 4;                               // DMA rounds per patch (512 lanes x 16 B each)
+    constexpr int PBUF = PROUNDS * 512 * 8;                  // halfs per patch buffer (32 KB)
+    constexpr int WT = BNB * LDSH;                           // halfs per weight buffer (40 KB)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * PBUF + 2 * WT];     // 144 KB
+    half_t* const Pb = smem;
+    half_t* const Wb = smem + 2 * PBUF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nt_n = p.N / BNB;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lid % nt_n, tm = lid / nt_n;
+    const int m0 = tm * BMB, n0 = tn * BNB;
+    const int Wd = p.Wo, PW = Wd + 2, Himg = p.Ho;
+    const int R = BMB / Wd;
+    const int gr0 = m0 / Wd;                                 // first image row of the tile in the stack of all images
+    const int bnd = (gr0 / Himg + 1) * Himg;                 // next image boundary
+    const bool straddle = bnd < gr0 + R;
+    const int pz = straddle ? bnd - gr0 + 1 : (1 << 30);     // patch row that is the inserted zero row
+    const int nprow = R + 2 + (straddle ? 1 : 0);
+    const int npieces = nprow * PW * 4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const half_t* zp = uv_zero_page;
+    auto glds16 = [&](const half_t* src, half_t* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    // ---- patch staging geometry (independent of the slab): source pixel index (-1: zero) and logical chunk per round
+    int ppix[PROUNDS], pch[PROUNDS];
+#pragma unroll
+    for (int i = 0; i < PROUNDS; ++i) {
+        const int q = i * 512 + tid;
+        const int pp = q >> 2, cst = q & 3;
+        const int py = pp / PW, px = pp - py * PW;
+        bool ok = q < npieces && px >= 1 && px <= Wd && py != pz;
+        const int gr = gr0 - 1 + py - (py > pz ? 1 : 0);
+        if (py == 0 && gr0 % Himg == 0) ok = false;                      // top padding of an image
+        if (py == nprow - 1 && (gr0 + R) % Himg == 0) ok = false;        // bottom padding
+        const int img = gr / Himg, yy = gr - img * Himg;                 // fused nearest x2 upsample (p.up): source pixel = (y >> 1, x >> 1)
+        ppix[i] = ok ? (img * p.Hs + (yy >> p.up)) * p.Ws + ((px - 1) >> p.up) : -1;
+        pch[i] = (cst ^ (((pp >> 2) & 1) << 1)) * 8;
+    }
+    auto issue_patch = [&](int slab) {
+        const int c0 = slab * 32;
+        const bool src2 = c0 >= p.C1;
+        const half_t* base = src2 ? p.X2 : p.X;
+        const int cs = src2 ? p.C2 : p.C1;
+        const int co = src2 ? c0 - p.C1 : c0;
+        half_t* dst = Pb + (slab & 1) * PBUF + wave_u * 64 * 8;
+#pragma unroll
+        for (int i = 0; i < PROUNDS; ++i)
+            if (i * 512 < npieces) glds16(ppix[i] >= 0 ? base + (long)ppix[i] * cs + co + pch[i] : zp, dst + i * 512 * 8);
+    };
+    // ---- weight staging (as gemm_big_kernel): rows rb + 64 i, chunk kc, XOR-swizzled with the row
+    const int rb = tid >> 3;
+    const int kc = (tid & 7) ^ (rb & 7);
+    unsigned woff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) woff[i] = (unsigned)((long)(n0 + rb + 64 * i) * p.K + kc * 8);
+    auto issue_w = [&](int t) {
+        half_t* dst = Wb + (t & 1) * WT + wave_u * 8 * LDSH;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) glds16(p.W32 + woff[i] + t * 64, dst + 64 * i * LDSH);
+    };
+
+    // ---- fragment geometry: patch pixel (tap 0,0) of this lane's row in each of the wave's MJ fragments
+    int pbase[MJ];
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        const int ml = wm * 16 * MJ + j * 16;
+        const int ry = ml / Wd, rx = ml - ry * Wd;
+        pbase[j] = (ry + ((straddle && gr0 + ry >= bnd) ? 1 : 0)) * PW + rx + l15;
+    }
+
+    f4 acc[NF][MJ];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nslab = (p.C1 + p.C2) / 32;
+    const int T = nslab * 9 / 2;
+    issue_patch(0);
+    if (nslab > 1) issue_patch(1);
+    issue_w(0);
+    int next_patch = 2;
+    int u_slab = 0, u_tap = 0;
+    const int sw = l15 & 7;
+    for (int t = 0; t < T; ++t) {
+        __syncthreads();                  // vmcnt(0) + barrier: everything issued so far landed; tile t-1 is consumed everywhere
+        if (next_patch < nslab && 9 * (next_patch - 1) <= 2 * t) {     // slab next_patch-2 is fully consumed: refill its buffer
+            issue_patch(next_patch);
+            ++next_patch;
+        }
+        const half_t* Ws = Wb + (t & 1) * WT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == p.issue_mode && t + 1 < T) issue_w(t + 1);     // A/B aid UNIVST_CONV_PATCH_WISSUE: 0 = before the first k-half, 1 = before the second
+            const half_t* Ps = Pb + (u_slab & 1) * PBUF;
+            const int ky = u_tap / 3, kx = u_tap - 3 * ky;
+            const int delta = ky * PW + kx;
+            const int ch = ((ks * 4 + g) ^ sw) * 8;
+            h8 a[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * 160 + i * 16 + l15) * LDSH + ch]);
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                const int pp = pbase[j] + delta;
+                const h8 b = *reinterpret_cast<const h8*>(&Ps[pp * 32 + ((g ^ (((pp >> 2) & 1) << 1)) << 3)]);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b, acc[i][j], 0, 0, 0);
+            }
+            if (++u_tap == 9) { u_tap = 0; ++u_slab; }
+        }
+    }
+    if (p.epi_lds) {
+        __syncthreads();
+        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane);
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        f4 col[NF];
+#pragma unroll
+        for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
+        gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MJ + j * 16 + l15, n0 + wn * 160, g);
+    }
+}
+
+
 // y[m][n] = sum_k act(x[m][k]) W[n][k] + b[n], M <= 8: one wave per output column (time embeddings).
 __global__ __launch_bounds__(256) void linear_small_kernel(const half_t* __restrict__ x, const half_t* __restrict__ W,
                                                            const half_t* __restrict__ b, half_t* __restrict__ y,
@@ -644,6 +798,12 @@ static int uv_pick_splits(long ntiles, int nk, long slots, int min_ktps, int max
     return best_s;
 }
 
+// LDS-patch 3x3 conv (conv_patch_kernel): whole image rows per tile, 16-pixel fragments inside one image row, patch <= 512 pixels
+static bool uv_conv_patch_eligible(const GemmParams& p, int bmb) {
+    return p.W32 && p.taps == 9 && p.stride == 1 && p.C1 % 32 == 0 && p.C2 % 32 == 0 && (p.C1 + p.C2) % 64 == 0 && p.N % 320 == 0 && p.Wo % 16 == 0 &&
+           bmb % p.Wo == 0 && p.M % bmb == 0 && bmb / p.Wo <= p.Ho && (bmb / p.Wo + 3) * (p.Wo + 2) <= 512 && !p.geglu;
+}
+
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
@@ -677,8 +837,12 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             const int sp = uv_pick_splits(nblk, nk, uv_num_cus(), 24, 8, 2.2, (double)p.M * p.N * 4.0);
             if (sp >= 2 && nblk * sp >= 128 && (size_t)sp * p.M * p.N * sizeof(float) <= UV_SPLITK_WS_BYTES) bsplits = sp;
         }
+        static const int patch_env = getenv("UNIVST_CONV_PATCH") ? atoi(getenv("UNIVST_CONV_PATCH")) : 1;
+        const bool use_patch = patch_env && mode == 1 && bsplits == 1 && nblk >= bigmin && uv_conv_patch_eligible(p, use192 ? 192 : 256);
+        UV_REQUIRE(p.W || use_patch, "conv: only the [Cin/32][9][32] weight copy was given but the problem is not eligible for the LDS-patch kernel "
+                   "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles)");
         if (!nobig && p.N % 320 == 0 && (nblk >= bigmin || bsplits > 1) && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
-            uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : UV_CLS_CONV_BIG, 2.0 * p.M * (double)p.N * p.K,
+            uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K,
                           2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
             // row-contiguous epilogue through LDS needs 16-byte aligned rows everywhere it touches; it pays for the plain
             // and residual epilogues (-12..19 % at K=320) but not for GEGLU, whose stores are half as many (UNIVST_GEMM_EPI=2 forces it)
@@ -708,6 +872,17 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                 }
             }
             const dim3 bgrid((unsigned)(nblk * q.splits));
+            if (use_patch) {
+                static const int wissue = getenv("UNIVST_CONV_PATCH_WISSUE") ? atoi(getenv("UNIVST_CONV_PATCH_WISSUE")) : 1;
+                q.issue_mode = wissue ? 1 : 0;
+            }
+            if (use_patch) {          // 3x3 / stride 1 on whole image rows: input patch in LDS, k order [Cin/32][9][32] (p.W32)
+                if (use192) hipLaunchKernelGGL((conv_patch_kernel<3>), bgrid, dim3(512), 0, stream, q);
+                else hipLaunchKernelGGL((conv_patch_kernel<4>), bgrid, dim3(512), 0, stream, q);
+                uv_prof_end(stream);
+                UV_LAUNCH_CHECK();
+                return UV_OK;
+            }
             if (use192) {
                 if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0, 3>), bgrid, dim3(512), 0, stream, q);
                 else hipLaunchKernelGGL((gemm_big_kernel<1, 3>), bgrid, dim3(512), 0, stream, q);

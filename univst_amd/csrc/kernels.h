@@ -7,6 +7,7 @@ struct GemmParams {
     const half_t* X = nullptr;   // MODE 0: [M,K] (row stride ldx).  MODE 1: NHWC source 1 [imgs, Hs, Ws, C1]
     const half_t* X2 = nullptr;  // MODE 1: NHWC source 2 (virtual channel concat) or null
     const half_t* W = nullptr;   // [N,K], K contiguous (conv: K = tap*(C1+C2)+c)
+    const half_t* W32 = nullptr; // optional second copy of a 3x3 conv weight in the k order [Cin/32][9][32] (LDS-patch kernel)
     half_t* Y = nullptr;
     long ldx = 0, ldy = 0;
     int M = 0, N = 0, K = 0;
@@ -101,13 +102,15 @@ enum {
     UV_CLS_CONV_BIG = 1,    // gemm_big_kernel<1>
     UV_CLS_GEMM = 2,        // gemm_kernel<*,0,...>
     UV_CLS_CONV = 3,        // gemm_kernel<*,1,...>
-    UV_CLS_ATTN_D40 = 4,    // attn_pp40_kernel<true> (long sequences) / attn_kernel_occ3<64,3,2>
+    UV_CLS_ATTN_D40 = 4,    // attn_pp40_kernel<true>: head_dim 40 self-attention over >= 2048 queries (the 64x64 level)
     UV_CLS_ATTN_D80 = 5,    // attn_kernel*<96,5,*>
     UV_CLS_ATTN_OTHER = 6,  // remaining attention instantiations
     UV_CLS_GROUPNORM = 7,
     UV_CLS_LAYERNORM = 8,
     UV_CLS_ADAIN = 9,
-    UV_NCLS = 10
+    UV_CLS_ATTN_TEXT = 10,  // the 77-key text cross-attention launches (any head_dim): reported apart from the self-attention
+    UV_CLS_CONV_PATCH = 11, // conv_patch_kernel<*>: 3x3 / stride-1 convs from an input patch kept in LDS
+    UV_NCLS = 12
 };
 void uv_prof_enable(int on);
 bool uv_prof_on();

@@ -18,7 +18,10 @@ namespace {
 // order (deterministic).
 __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* __restrict__ s2, int C1, int C2,
                                   int rows_per_stat, int rows_per_chunk, int G, float* __restrict__ part) {
-    extern __shared__ float sm[];                    // [TR][C] sums, [TR][C] sumsq
+    // Sums are taken about a per-thread, per-channel PIVOT (the first value the thread reads): sum (x-p) and sum (x-p)^2 stay
+    // of the order of the spread even when |mean| >> std (real SD checkpoints have such channel groups), where a raw
+    // one-pass E[x^2] - mean^2 in fp32 cancels.  The block recombines them about zero in double, in a fixed order.
+    extern __shared__ float sm[];                    // [TR][C] shifted sums, [TR][C] shifted sumsq, [TR][C] pivots
     const int C = C1 + C2, TC = C / 8, TR = blockDim.x / TC;
     const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
     const int s = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
@@ -26,14 +29,19 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
     const bool second = c0 >= C1;
     const half_t* src = second ? s2 : s1;
     const int cs = second ? C2 : C1, co = second ? c0 - C1 : c0;
-    float sum[8], sq[8];
+    const int r0 = chunk * rows_per_chunk;
+    const int r1 = min(r0 + rows_per_chunk, rows_per_stat);
+    float sum[8], sq[8], pv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+    for (int e = 0; e < 8; ++e) sum[e] = sq[e] = pv[e] = 0.f;
     if (tr < TR) {
         const long rbase = (long)s * rows_per_stat;
-        const int r0 = chunk * rows_per_chunk;
-        const int r1 = min(r0 + rows_per_chunk, rows_per_stat);
         int r = r0 + tr;
+        if (r < r1) {
+            h8 v = *reinterpret_cast<const h8*>(src + (rbase + r) * cs + co);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = (float)v[e];
+        }
         for (; r + 3 * TR < r1; r += 4 * TR) {
             h8 v[4];
 #pragma unroll
@@ -42,7 +50,7 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float f = (float)v[q][e];
+                    float f = (float)v[q][e] - pv[e];
                     sum[e] += f;
                     sq[e] += f * f;
                 }
@@ -51,7 +59,7 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
             h8 v = *reinterpret_cast<const h8*>(src + (rbase + r) * cs + co);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float f = (float)v[e];
+                float f = (float)v[e] - pv[e];
                 sum[e] += f;
                 sq[e] += f * f;
             }
@@ -60,20 +68,24 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
         for (int e = 0; e < 8; ++e) {
             sm[tr * C + c0 + e] = sum[e];
             sm[(TR + tr) * C + c0 + e] = sq[e];
+            sm[(2 * TR + tr) * C + c0 + e] = pv[e];
         }
     }
     __syncthreads();
     const int cpg = C / G;
     for (int gi = threadIdx.x; gi < G; gi += blockDim.x) {
-        float a = 0.f, b = 0.f;
+        double a = 0.0, b = 0.0;
         for (int c = gi * cpg; c < (gi + 1) * cpg; ++c)
             for (int t = 0; t < TR; ++t) {
-                a += sm[t * C + c];
-                b += sm[(TR + t) * C + c];
+                const int first = r0 + t;
+                const double n = first < r1 ? (double)((r1 - first + TR - 1) / TR) : 0.0;      // rows this thread-row visited
+                const double p = sm[(2 * TR + t) * C + c], ds = sm[t * C + c], dq = sm[(TR + t) * C + c];
+                a += n * p + ds;
+                b += dq + 2.0 * p * ds + n * p * p;
             }
         float* o = part + (((long)s * nchunk + chunk) * G + gi) * 2;
-        o[0] = a;
-        o[1] = b;
+        o[0] = (float)a;
+        o[1] = (float)b;
     }
 }
 
@@ -160,10 +172,11 @@ __global__ __launch_bounds__(256) void gn_reduce_chunks_kernel(const float* __re
     const int lane = threadIdx.x & 63;
     if (i >= SG2) return;
     const int s = i / G2, r = i - s * G2;
-    float a = 0.f;
-    for (int c = lane; c < nchunk; c += 64) a += part[((long)s * nchunk + c) * G2 + r];
-    a = wave_sum(a);
-    if (lane == 0) red[i] = a;
+    double a = 0.0;                                   // (sum, sumsq about zero: cancellation-prone, keep the chunk walk in double)
+    for (int c = lane; c < nchunk; c += 64) a += (double)part[((long)s * nchunk + c) * G2 + r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) red[i] = (float)a;
 }
 
 // LayerNorm over the last dim, one wave per row, row kept in registers (two-pass variance).
@@ -263,7 +276,7 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     const int rpc = (rows_per_stat + nchunk - 1) / nchunk;
     nchunk = (rows_per_stat + rpc - 1) / rpc;
     uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
-    size_t lds1 = (size_t)2 * TR * C * sizeof(float);
+    size_t lds1 = (size_t)3 * TR * C * sizeof(float);
     UV_REQUIRE(lds1 <= 160 * 1024, "groupnorm: LDS %zu too large", lds1);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, S), dim3(block), lds1, stream, s1, s2, C1, C2, rows_per_stat, rpc,
                        G, part);

@@ -49,6 +49,17 @@ __global__ void permute_conv_weight_ti_kernel(const half_t* __restrict__ in, hal
     int o = (int)(i / ((long)Ci * 9));
     out[i] = in[((long)o * Ci + q * 64 + j) * 9 + t];
 }
+// [Co,Ci,3,3] -> [Co][Ci/32][9][32] (conv_patch_kernel: a k tile is two consecutive (32-channel slab, tap) units)
+__global__ void permute_conv_weight_t32_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int Co, int Ci) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)Co * Ci * 9;
+    if (i >= total) return;
+    int j = (int)(i % 32);
+    int t = (int)((i / 32) % 9);
+    int q = (int)((i / (32 * 9)) % (Ci / 32));
+    int o = (int)(i / ((long)Ci * 9));
+    out[i] = in[((long)o * Ci + q * 32 + j) * 9 + t];
+}
 // GEGLU row interleave: out row (32q + j) = in row (16q + j), out row (32q+16+j) = in row (half + 16q + j)
 __global__ void geglu_interleave_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int rows, int cols) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,6 +245,12 @@ int UNet::finalize(hipStream_t s) {
                 rc = derive_alloc(k + "#ti", {Co, Ci / 64, 9, 64}, &d2);
                 if (rc) return rc;
                 hipLaunchKernelGGL(permute_conv_weight_ti_kernel, dim3(nb((long)Co * Ci * 9)), dim3(256), 0, s, t.ptr, d2, Co, Ci);
+            }
+            if (taps == 9 && Ci % 64 == 0 && Co % 320 == 0 && k.find("downsamplers") == std::string::npos) {      // LDS-patch copy (GemmParams::W32; stride-1 convs)
+                half_t* d3;
+                rc = derive_alloc(k + "#t32", {Co, Ci / 32, 9, 32}, &d3);
+                if (rc) return rc;
+                hipLaunchKernelGGL(permute_conv_weight_t32_kernel, dim3(nb((long)Co * Ci * 9)), dim3(256), 0, s, t.ptr, d3, Co, Ci);
             }
         } else if (ends(k, ".attn1.to_q.weight")) {
             std::string p = k.substr(0, k.size() - strlen("to_q.weight"));
@@ -449,6 +466,7 @@ struct Fwd {
         g.K = taps * (g.C1 + g.C2);
         g.korder = (taps == 9 && g.C1 % 64 == 0 && g.C2 % 64 == 0 && u.find(p + ".weight#ti")) ? 1 : 0;
         g.W = W(p + (g.korder ? ".weight#ti" : ".weight#nhwc"));
+        if (taps == 9 && stride == 1 && u.find(p + ".weight#t32")) g.W32 = W(p + ".weight#t32");
         g.bias = W(p + ".bias");
         g.rowbias = rowbias;
         g.ldrb = ldrb;

@@ -2,8 +2,10 @@
 
 Everything here is host orchestration over HIP kernels (univst_amd._native): per step it enqueues the mask
 blend, the optional latent AdaIN, one native UNet forward (the whole graph is one C-ABI call) and the DDIM
-update; nothing synchronises with the host inside the loop.  Inversion latents and masks are device-resident
-for the whole loop (the reference re-reads them from disk every step: stable_diffusion.py:683-698).
+update; the scheduler's timesteps are read to the host once before the loop, so nothing inside it synchronises
+with the host even when a caller keeps them on the GPU (``set_timesteps(n, device=...)`` as the reference pipeline
+does).  Inversion latents and masks are device-resident for the whole loop (the reference re-reads them from disk
+every step: stable_diffusion.py:683-698).
 """
 from typing import Callable, List, Optional, Sequence
 
@@ -91,8 +93,13 @@ def transfer_loop(pipe, latents: torch.Tensor, text3: torch.Tensor, content_inv:
     if mask_u8 is not None:
         mk = mask_u8.to(dev).to(torch.uint8).reshape(-1, *mask_u8.shape[-2:]).contiguous()
         m = _native.mask_resize(mk, latents.shape[-2], latents.shape[-1])
-    eta2 = getattr(unet.up_blocks[1].attentions[1].transformer_blocks[0].attn1, "eta2", 0.5)
-    for i, t in enumerate(sched.timesteps):
+    eta2 = 0.5
+    if skip_dead_branches:
+        register_time(pipe, 0)
+        st = unet._pnp_state()       # validates that all eight PnP layers agree (raises otherwise) and returns their window
+        eta2 = float(st.eta2) if st is not None else -1.0     # no PnP registered: the branches never interact
+    timesteps = [int(t) for t in sched.timesteps.tolist()]          # one D2H copy at most, before the loop
+    for i, t in enumerate(timesteps):
         c_t, s_t = cinv[n - i], sinv[n - i]
         if m is not None and i <= 0.9 * n:
             latents = _native.mask_blend(latents, c_t, m)
@@ -108,7 +115,7 @@ def transfer_loop(pipe, latents: torch.Tensor, text3: torch.Tensor, content_inv:
             eps = smoother(i, t, latents, eps)
         latents = ddim_step(sched, eps, t, latents)
         if callback is not None:
-            callback(i, t, latents)
+            callback(i, sched.timesteps[i], latents)
     return latents
 
 
@@ -129,8 +136,9 @@ def inversion_loop(pipe, sched, latent: torch.Tensor, text1: torch.Tensor, num_i
     if on_latent:
         on_latent(0, latent)
     last_latent = None
+    timesteps = [int(t) for t in sched.timesteps.tolist()]
     for i in range(num_inv_steps):
-        t = sched.timesteps[len(sched.timesteps) - i - 1]
+        t = timesteps[len(timesteps) - i - 1]
         eps = pipe.unet(latent, t, encoder_hidden_states=text1, ft_indices=ft_indices, ft_timesteps=ft_timesteps,
                         ft_path=ft_path)["sample"]
         if easy_inv and (0.05 + 0.2) * 50 > i > 0.05 * 50 and i > 0:

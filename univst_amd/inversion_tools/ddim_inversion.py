@@ -35,11 +35,11 @@ def content_inversion_reconstruction(pipe, ddim_inv_scheduler, content_path, inv
 
 def style_inversion_reconstruction(pipe, ddim_inv_scheduler, style_path, inversion_path, reconstruction_path, num_frames, height,
                                    width, time_steps, weight_dtype, ft_indices=None, ft_timesteps=None, ft_path=None,
-                                   is_opt=False, reconstruct=True):
+                                   is_opt=True, reconstruct=True):
     """ddim_inversion.py:45-65: the style image repeated num_frames times."""
-    from ..src.util import load_image
     import numpy as np
-    img = load_image(style_path, image_size=(width, height))
+    from PIL import Image
+    img = Image.open(style_path).convert("RGB").resize((width, height))      # ddim_inversion.py:48 (no EXIF handling, RGB first)
     px = torch.from_numpy((np.array(img) / 127.5) - 1.0).permute(2, 0, 1).float()
     pixel_values = px.unsqueeze(0).repeat(num_frames, 1, 1, 1).to(weight_dtype).cuda()
     latents = _encode_frames(pipe, pixel_values, num_frames)

@@ -53,43 +53,72 @@ class FrameShard:
 
     # ------------------------------------------------------------------ native hooks
     def attach(self, unet, max_tokens: int = 4096, max_channels: int = None, branches: int = 3):
-        """register the comm callbacks + workspace on the UNet's native handle (no-op for world == 1)."""
+        """register the comm callbacks + workspace on the UNet's native handle (no-op for world == 1).  ``max_tokens`` is
+        only the initial size: UNet.forward calls ``ensure`` with the real latent size and the workspace grows on demand;
+        a rebuilt native handle (``.half()``, ``load_state_dict`` ...) is re-registered the same way."""
         if self.world == 1:
             return
         if self.comm is None:
             import torch.distributed as dist
             self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
+        self._branches, self._max_channels = branches, max_channels
+        self._tokens, self._handle = 0, None
+        self.error = None
+        unet._frame_shard = self
         unet._sync_native()
+        self.ensure(unet, max_tokens)
+
+    def ensure(self, unet, tokens: int):
+        """called by UNet.forward before every native call: the comm hooks are on the CURRENT native handle and the
+        workspace holds the largest K|V pack of a ``tokens``-token latent."""
+        if self.world == 1:
+            return
+        handle = unet._native_handle
+        if handle is self._handle and tokens <= self._tokens:
+            return
+        tokens = max(tokens, self._tokens)
         boc = unet.config.block_out_channels
-        cmax = max_channels or max(boc)
         # largest K|V pack: B * N * 2C fp16 over the attention levels (N shrinks 4x per level while C grows <= 2x)
-        pack = max(branches * (max_tokens >> (2 * i)) * 2 * c * 2 for i, c in enumerate(boc[:3]))
+        pack = max(self._branches * (tokens >> (2 * i)) * 2 * c * 2 for i, c in enumerate(boc[:3]))
         nbytes = 65536 + 4 * ((pack + 255) // 256 * 256) + 4096
-        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=unet.device)
-        ws, comm = self.ws, self.comm
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=unet.device)
+        nbytes = self.ws.numel()
+        shard = self
 
         def allreduce(user, byte_off, count):
             try:
-                comm.all_reduce_sum(ws[byte_off:byte_off + 4 * count].view(torch.float32))
+                shard.comm.all_reduce_sum(shard.ws[byte_off:byte_off + 4 * count].view(torch.float32))
                 return 0
-            except Exception as e:  # pragma: no cover
-                print(f"[univst_amd.parallel] all-reduce failed: {e!r}")
+            except BaseException as e:      # never unwind through the C frames: report, the native call returns an error
+                shard.error = e
                 return 1
 
         def kv_exchange(user, off_send, off_first, off_prev, off_rfirst, nb):
             try:
-                comm.halo_and_broadcast(ws[off_send:off_send + nb], ws[off_first:off_first + nb], ws[off_prev:off_prev + nb],
-                                        ws[off_rfirst:off_rfirst + nb])
+                w = shard.ws
+                shard.comm.halo_and_broadcast(w[off_send:off_send + nb], w[off_first:off_first + nb], w[off_prev:off_prev + nb],
+                                              w[off_rfirst:off_rfirst + nb])
                 return 0
-            except Exception as e:  # pragma: no cover
-                print(f"[univst_amd.parallel] K/V exchange failed: {e!r}")
+            except BaseException as e:
+                shard.error = e
                 return 1
 
         ar, kv = _native.ALLREDUCE_FN(allreduce), _native.KVEXCHANGE_FN(kv_exchange)
-        self._keep += [ar, kv]
-        _native.check(_native.load().univst_unet_set_comm(unet._native_handle, self.rank, self.world, ws.data_ptr(), nbytes, ar, kv,
-                                                          None), "unet_set_comm")
-        unet._frame_shard = self
+        self._keep = [ar, kv]
+        _native.check(_native.load().univst_unet_set_comm(handle, self.rank, self.world, self.ws.data_ptr(), nbytes, ar, kv, None),
+                      "unet_set_comm")
+        self._tokens, self._handle = tokens, handle
+
+    def raise_pending(self, what: str):
+        """a collective failed inside a native call: surface the original exception on THIS rank right away (the process
+        then dies and the launcher tears the job down) instead of leaving the peers blocked behind a swallowed error."""
+        if getattr(self, "error", None) is not None:
+            e, self.error = self.error, None
+            abort = getattr(self.comm, "abort", None)
+            if abort is not None:
+                abort()
+            raise RuntimeError(f"{what}: collective failed on rank {self.rank}/{self.world}") from e
 
     # ------------------------------------------------------------------ sharded latent_adain (pnp_utils.py:128-139)
     def latent_adain(self, cnt: torch.Tensor, sty: torch.Tensor) -> torch.Tensor:

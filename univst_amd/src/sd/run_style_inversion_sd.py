@@ -21,7 +21,7 @@ def main(a):
     os.makedirs(rec, exist_ok=True)
     with torch.no_grad():
         style_inversion_reconstruction(pipe, inv_sched, a.style_path, inv, rec, a.num_frames, a.height, a.width, a.time_steps,
-                                       a.weight_dtype, is_opt=False, reconstruct=not a.skip_reconstruction)
+                                       a.weight_dtype, is_opt=a.is_opt, reconstruct=not a.skip_reconstruction)
 
 
 def parser():
@@ -31,6 +31,7 @@ def parser():
     p.add_argument("--num_frames", type=int, default=16)
     p.add_argument("--height", type=int, default=512)
     p.add_argument("--width", type=int, default=512)
+    p.add_argument("--is_opt", action="store_true", help="use Easy-Inv")
     p.add_argument("--skip_reconstruction", action="store_true")
     return p
 
