@@ -160,6 +160,9 @@ int univst_maskprop_finalize(const float* segs, uint8_t* mask_out, int ncls, int
  * by fwd, occluded pixels take `key`.  key/now uint8 [H,W,3], fwd/bwd f32 [H,W,2]. */
 int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int H,
                            int W, float threshold, void* stream);
+/* latent-space sliding window (no reference code exists for it — definition in csrc/warp.hip and DESIGN.md):
+ * x0 [C,F,h,w] fp16 in place, lflow [F, 2r+1, h, w, 2] fp32 = flow from frame k to frame k+b in latent-pixel units. */
+int univst_latent_window_smooth(void* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, void* stream);
 int univst_accumulate_u8(const uint8_t* frame, float* acc, int64_t n, void* stream);
 /* dst[i] = (uint8) trunc(acc[i] / weight) */
 int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n, void* stream);

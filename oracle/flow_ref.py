@@ -105,3 +105,42 @@ def sliding_window_smooth(frames: np.ndarray, flow_fn: Callable, mask01: Optiona
         m = mask01[None, :].astype(np.uint8)
         est = ori * m + (1 - m) * est
     return est
+
+
+def latent_sliding_window_smooth(x0: np.ndarray, lflow: np.ndarray, mask_m: Optional[np.ndarray], r: int = 2,
+                                 threshold: float = 1.5 / 8) -> np.ndarray:
+    """Latent-space sliding window.  NOT a restatement of reference code — the reference only describes it
+    (README.md:59) and implements the pixel variant; this is the definition univst_amd ships behind smoother='latent',
+    written out independently of the kernel for the parity test: x0 [1,C,F,h,w] float32, lflow [F,2r+1,h,w,2] (flow from
+    frame k to k+b in latent pixels), mask_m [F,h,w] in [0,1] (1 keeps the un-smoothed latent)."""
+    est = x0.astype(np.float32).copy()
+    ori = est.copy()
+    _, C, F, h, w = est.shape
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+    for key in range(F):
+        acc = est[0, :, key].copy()
+        weight = 1.0
+        for b in range(-r, r + 1):
+            now = key + b
+            if b == 0 or now < 0 or now >= F:
+                continue
+            fwd, bwd = lflow[key, b + r], lflow[now, r - b]
+            e = fwd + bwd
+            occ = np.sqrt(e[..., 0] ** 2 + e[..., 1] ** 2) > threshold
+            sx, sy = xs + fwd[..., 0], ys + fwd[..., 1]
+            ix, iy = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
+            ax, ay = sx - ix, sy - iy
+            src = est[0, :, now]
+
+            def tap(yy, xx):
+                ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+                return src[:, np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)] * ok[None]
+            warped = (tap(iy, ix) * ((1 - ax) * (1 - ay))[None] + tap(iy, ix + 1) * (ax * (1 - ay))[None]
+                      + tap(iy + 1, ix) * ((1 - ax) * ay)[None] + tap(iy + 1, ix + 1) * (ax * ay)[None])
+            acc = acc + np.where(occ[None], est[0, :, key], warped)
+            weight += 1.0
+        est[0, :, key] = (acc / weight).astype(np.float16).astype(np.float32)      # the product stores fp16
+    if mask_m is not None:
+        m = mask_m[None, None].astype(np.float32)
+        est = (1 - m) * est + m * ori
+    return est

@@ -5,7 +5,8 @@ Same constructor, same ``reconstruction`` / ``video_style_transfer`` signatures,
 The denoising loops run through univst_amd.engine (HIP kernels; device-resident latents/masks); the VAE and
 the CLIP text encoder stay stock PyTorch-ROCm modules supplied by the caller (third-party weights).
 Extras (all optional, reference defaults unchanged): ``smoother='pixel'`` + ``flow_fn`` switch on the
-sliding-window smoothing that is dead code in the reference (:715), ``content_inv_latents`` /
+sliding-window smoothing that is dead code in the reference (:715), ``smoother='latent'`` + ``latent_flows`` the
+latent-space variant the reference's README describes but does not implement, ``content_inv_latents`` /
 ``style_inv_latents`` / ``masks`` accept in-memory tensors instead of paths, ``output_type='latent'`` skips
 the VAE, ``skip_dead_branches`` (see engine.transfer_loop).
 """
@@ -153,7 +154,7 @@ class SpatioTemporalStableDiffusionPipeline:
                              generator=None, latents=None, output_type="tensor", return_dict=True, callback=None,
                              callback_steps=1, content_inv_path=None, style_inv_path=None, mask_path=None,
                              content_inv_latents=None, style_inv_latents=None, masks=None, smoother=None, flow_fn=None,
-                             skip_dead_branches=False, **kwargs):
+                             latent_flows=None, skip_dead_branches=False, **kwargs):
         if eta != 0.0:
             raise NotImplementedError("eta != 0")
         device = self._execution_device
@@ -169,7 +170,20 @@ class SpatioTemporalStableDiffusionPipeline:
         if masks is None and mask_path:
             masks = load_mask(mask_path, n_frames=F_)
         sm = None
-        if smoother is not None:
+        if smoother == "latent":
+            # SURVEY §8f-2 (README.md:59 of the reference; no reference code): warp + window blend on the x0 latents themselves
+            # with the content clip's flows at latent resolution — no VAE decode / encode and no RAFT call inside the loop
+            if latent_flows is None or masks is None:
+                raise ValueError("smoother='latent' needs latent_flows (src.cal_optica_flow.make_latent_flows on the content frames) and masks")
+            from ....src.cal_optica_flow import latent_sliding_window_smooth
+            from .... import _native
+            lf = latent_flows.to(device=device, dtype=torch.float32).contiguous()
+            mm = _native.mask_resize(masks.to(device).to(torch.uint8).reshape(-1, *masks.shape[-2:]).contiguous(), latents.shape[-2], latents.shape[-1])
+
+            def sm(i, t, lat, eps):
+                x0 = engine.pred_original_sample(self.scheduler, eps, t, lat)
+                return engine.return_to_timestep(self.scheduler, t, lat, latent_sliding_window_smooth(x0, lf, mm))
+        elif smoother is not None:
             if smoother != "pixel":
                 print("error")
                 return

@@ -218,6 +218,10 @@ int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* 
     UV_REQUIRE(key && now && fwd && bwd && acc, "warp_accumulate: null argument");
     return uv_launch_warp_accumulate(key, now, fwd, bwd, acc, Hh, W, thr, S(s));
 }
+int univst_latent_window_smooth(void* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, void* s) {
+    UV_REQUIRE(x0 && lflow, "latent_window_smooth: null argument");
+    return uv_launch_latent_window_smooth(HM(x0), lflow, C, F, h, w, r, thr, S(s));
+}
 int univst_accumulate_u8(const uint8_t* f, float* acc, int64_t n, void* s) {
     UV_REQUIRE(f && acc, "accumulate_u8: null argument");
     return uv_launch_accumulate_u8(f, acc, n, S(s));

@@ -65,7 +65,67 @@ __global__ void window_store_kernel(const float* __restrict__ acc, float weight,
     }
 }
 
+// ---- latent-space variant of the sliding window (README.md:59 of the reference describes smoothing "in the
+// latent space", its code only has the pixel variant, so THIS definition is ours and has no reference oracle):
+// one launch per key frame k (Gauss-Seidel like the pixel loop: k sees the already smoothed k-2, k-1):
+//   est[k] <- mean over b in [-r, r], 0 <= k+b < F of  (b == 0 ? est[k] : occluded ? est[k] : bilinear(est[k+b], p + fwd))
+//   fwd = lflow[k][b+r], bwd = lflow[k+b][r-b] (flows in latent-pixel units, added at the same pixel like
+//   cal_optica_flow.py:20-29), occluded iff |fwd + bwd|_2 > thr, bilinear taps outside the latent are zero.
+// x0 is [C, F, h, w] fp16 (the pipeline's [1,C,F,h,w] pred_original_sample), updated in place.
+__global__ __launch_bounds__(256) void latent_window_kernel(half_t* __restrict__ x0, const float* __restrict__ lflow, int C, int F, int h, int w,
+                                                            int r, int key, float thr) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int hw = h * w;
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const int nb = 2 * r + 1;
+    float acc[8], kv[8];
+    for (int c = 0; c < C; ++c) {
+        kv[c] = (float)x0[((long)c * F + key) * hw + p];
+        acc[c] = kv[c];
+    }
+    float weight = 1.f;
+    for (int b = -r; b <= r; ++b) {
+        const int now = key + b;
+        if (b == 0 || now < 0 || now >= F) continue;
+        const float* fw = lflow + (((long)key * nb + (b + r)) * hw + p) * 2;
+        const float* bw = lflow + (((long)now * nb + (r - b)) * hw + p) * 2;
+        const float fx = fw[0], fy = fw[1];
+        const float ex = fx + bw[0], ey = fy + bw[1];
+        weight += 1.f;
+        if (sqrtf(ex * ex + ey * ey) > thr) {
+            for (int c = 0; c < C; ++c) acc[c] += kv[c];
+            continue;
+        }
+        const float sx = (float)x + fx, sy = (float)y + fy;
+        const float flx = floorf(sx), fly = floorf(sy);
+        const int ix = (int)flx, iy = (int)fly;
+        const float ax = sx - flx, ay = sy - fly;
+        const bool x0ok = ix >= 0 && ix < w, x1ok = ix + 1 >= 0 && ix + 1 < w;
+        const bool y0ok = iy >= 0 && iy < h, y1ok = iy + 1 >= 0 && iy + 1 < h;
+        const float w00 = (1.f - ax) * (1.f - ay), w01 = ax * (1.f - ay), w10 = (1.f - ax) * ay, w11 = ax * ay;
+        for (int c = 0; c < C; ++c) {
+            const half_t* src = x0 + ((long)c * F + now) * hw;
+            const float v00 = (y0ok && x0ok) ? (float)src[iy * w + ix] : 0.f;
+            const float v01 = (y0ok && x1ok) ? (float)src[iy * w + ix + 1] : 0.f;
+            const float v10 = (y1ok && x0ok) ? (float)src[(iy + 1) * w + ix] : 0.f;
+            const float v11 = (y1ok && x1ok) ? (float)src[(iy + 1) * w + ix + 1] : 0.f;
+            acc[c] += v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+        }
+    }
+    for (int c = 0; c < C; ++c) x0[((long)c * F + key) * hw + p] = (half_t)(acc[c] / weight);
+}
+
 }  // namespace
+
+int uv_launch_latent_window_smooth(half_t* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, hipStream_t s) {
+    UV_REQUIRE(C >= 1 && C <= 8 && F >= 1 && r >= 1 && r <= 4, "latent_window_smooth: C=%d F=%d r=%d unsupported", C, F, r);
+    for (int key = 0; key < F; ++key) {       // sequential over key frames: frame k reads the already smoothed k-r .. k-1
+        hipLaunchKernelGGL(latent_window_kernel, dim3((unsigned)((h * w + 255) / 256)), dim3(256), 0, s, x0, lflow, C, F, h, w, r, key, thr);
+        UV_LAUNCH_CHECK();
+    }
+    return UV_OK;
+}
 
 int uv_launch_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int H, int W,
                               float thr, hipStream_t s) {

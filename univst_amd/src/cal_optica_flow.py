@@ -68,3 +68,38 @@ def sliding_window_smooth(frames, flow_fn, mask01=None, r=2):
         m = mask01.to(torch.bool)[..., None]
         est = torch.where(m, ori, est)
     return est.permute(3, 0, 1, 2).unsqueeze(0).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ latent-space variant
+@torch.no_grad()
+def make_latent_flows(frames_u8, flow_fn, r=2, down=8):
+    """flows of the CONTENT clip at latent resolution, computed once before the loop (the motion the smoother follows is the
+    content's; the pixel variant re-estimates it from every decoded x0: 116 RAFT inferences per step, stable_diffusion.py:743).
+    frames_u8 [F,H,W,3] uint8 (device) -> lflow [F, 2r+1, H/down, W/down, 2] fp32: flow from frame k to frame k+b averaged
+    over down x down pixel blocks and divided by `down` (latent-pixel units); slots with k+b outside the clip stay zero."""
+    F_, H, W, _ = frames_u8.shape
+    out = torch.zeros(F_, 2 * r + 1, H // down, W // down, 2, dtype=torch.float32, device=frames_u8.device)
+    for k in range(F_):
+        for b in range(-r, r + 1):
+            n = k + b
+            if b == 0 or n < 0 or n >= F_:
+                continue
+            f = flow_fn(frames_u8[k], frames_u8[n]).to(torch.float32)                        # [H,W,2]
+            f = torch.nn.functional.avg_pool2d(f.permute(2, 0, 1)[None], down)[0].permute(1, 2, 0) / down
+            out[k, b + r] = f
+    return out
+
+
+@torch.no_grad()
+def latent_sliding_window_smooth(x0, lflow, mask_m=None, r=2, threshold=1.5 / 8):
+    """latent-space sliding window (README.md:59 of the reference; our definition, see csrc/warp.hip):
+    x0 [1,C,F,h,w] fp16 (pred_original_sample), lflow from make_latent_flows, mask_m fp16 [F,h,w] (1 keeps the un-smoothed
+    latent, the polarity of stable_diffusion.py:751).  Returns the smoothed x0 (new tensor)."""
+    b, C_, F_, h, w = x0.shape
+    assert b == 1 and tuple(lflow.shape) == (F_, 2 * r + 1, h, w, 2)
+    est = x0.to(torch.float16).contiguous().clone()
+    _native.check(_native.load().univst_latent_window_smooth(est.data_ptr(), lflow.contiguous().data_ptr(), C_, F_, h, w, r,
+                                                             float(threshold), _native.stream_ptr()), "latent_window_smooth")
+    if mask_m is not None:
+        est = _native.mask_blend(est, x0.to(torch.float16).contiguous(), mask_m)
+    return est
