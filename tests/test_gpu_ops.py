@@ -212,6 +212,22 @@ def test_conv3x3_lds_patch_fused_upsample(nat):
     close(nat.conv3x3_patch(nhwc(x), conv_w_t32(w), bias=b, upsample=True), nhwc(ref))
 
 
+@pytest.mark.parametrize("C1,C2,Co,H,imgs", [(1280, 0, 640, 16, 12),      # 24 tiles x 5 splits over 64-channel slab pairs
+                                              (640, 640, 640, 16, 12),     # virtual concat, 24 tiles
+                                              (64, 0, 320, 64, 20)])       # M tail: 81920 rows = 426.67 tiles of 192
+def test_conv3x3_lds_patch_split_k_and_tail(nat, C1, C2, Co, H, imgs):
+    """few tiles + long reduction (single-branch / frame-shard shapes): split-K over 64-channel slab pairs with fp32 partials
+    and the epilogue in splitk_reduce_kernel; and a row count that is not a multiple of the tile height."""
+    x1 = rnd(imgs, C1, H, H, seed=1)
+    x2 = rnd(imgs, C2, H, H, seed=2) if C2 else None
+    w = rnd(Co, C1 + C2, 3, 3, seed=3, scale=1 / math.sqrt(9 * (C1 + C2)))
+    b, res = rnd(Co, seed=4), rnd(imgs, Co, H, H, seed=6)
+    xin = torch.cat([x1, x2], 1).float() if C2 else x1.float()
+    ref = F.conv2d(xin, w.float(), b.float(), padding=1) + res.float()
+    got = nat.conv3x3_patch(nhwc(x1), conv_w_t32(w), bias=b, x2=None if x2 is None else nhwc(x2), residual=nhwc(res))
+    close(got, nhwc(ref))
+
+
 def test_conv3x3_lds_patch_rejects_ineligible(nat):
     x = rnd(6, 32, 8, 8, seed=1)
     w = rnd(320, 32, 3, 3, seed=2)

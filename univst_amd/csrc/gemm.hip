@@ -616,10 +616,14 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     const int wn = wave & 1, wm = wave >> 1;
     const int l15 = lane & 15, g = lane >> 4;
     const int nt_n = p.N / BNB;
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntiles = nt_n * ((p.M + BMB - 1) / BMB);
+    const int split = lid / ntiles;                          // split-K over 64-channel slab pairs (p.ktps = 9 * pairs per split)
+    lid -= split * ntiles;
     const int tn = lid % nt_n, tm = lid / nt_n;
     const int m0 = tm * BMB, n0 = tn * BNB;
     const int Wd = p.Wo, PW = Wd + 2, Himg = p.Ho;
+    const int rows_total = p.M / Wd;                         // image rows in the stack of all images
     const int R = BMB / Wd;
     const int gr0 = m0 / Wd;                                 // first image row of the tile in the stack of all images
     const int bnd = (gr0 / Himg + 1) * Himg;                 // next image boundary
@@ -641,8 +645,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         const int q = i * 512 + tid;
         const int pp = q >> 2, cst = q & 3;
         const int py = pp / PW, px = pp - py * PW;
-        bool ok = q < npieces && px >= 1 && px <= Wd && py != pz;
         const int gr = gr0 - 1 + py - (py > pz ? 1 : 0);
+        bool ok = q < npieces && px >= 1 && px <= Wd && py != pz && gr < rows_total;
         if (py == 0 && gr0 % Himg == 0) ok = false;                      // top padding of an image
         if (py == nprow - 1 && (gr0 + R) % Himg == 0) ok = false;        // bottom padding
         const int img = gr / Himg, yy = gr - img * Himg;                 // fused nearest x2 upsample (p.up): source pixel = (y >> 1, x >> 1)
@@ -687,24 +691,28 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int nslab = (p.C1 + p.C2) / 32;
+    const int nslab_all = (p.C1 + p.C2) / 32;
+    const int s_begin = p.splits > 1 ? split * (p.ktps / 9) * 2 : 0;
+    const int s_end = p.splits > 1 ? (s_begin + (p.ktps / 9) * 2 < nslab_all ? s_begin + (p.ktps / 9) * 2 : nslab_all) : nslab_all;
+    const int nslab = s_end - s_begin;                       // slabs of THIS block (an even number)
     const int T = nslab * 9 / 2;
-    issue_patch(0);
-    if (nslab > 1) issue_patch(1);
-    issue_w(0);
-    int next_patch = 2;
-    int u_slab = 0, u_tap = 0;
+    const int t_off = s_begin * 9 / 2;                       // first k tile of this block in the weight's k order
+    issue_patch(s_begin);
+    if (nslab > 1) issue_patch(s_begin + 1);
+    issue_w(t_off);
+    int next_patch = 2;                                      // next slab to stage, relative to s_begin
+    int u_slab = s_begin, u_tap = 0;
     const int sw = l15 & 7;
     for (int t = 0; t < T; ++t) {
         __syncthreads();                  // vmcnt(0) + barrier: everything issued so far landed; tile t-1 is consumed everywhere
         if (next_patch < nslab && 9 * (next_patch - 1) <= 2 * t) {     // slab next_patch-2 is fully consumed: refill its buffer
-            issue_patch(next_patch);
+            issue_patch(s_begin + next_patch);
             ++next_patch;
         }
-        const half_t* Ws = Wb + (t & 1) * WT;
+        const half_t* Ws = Wb + ((t_off + t) & 1) * WT;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (ks == p.issue_mode && t + 1 < T) issue_w(t + 1);     // A/B aid UNIVST_CONV_PATCH_WISSUE: 0 = before the first k-half, 1 = before the second
+            if (ks == p.issue_mode && t + 1 < T) issue_w(t_off + t + 1);     // A/B aid UNIVST_CONV_PATCH_WISSUE: 0 = before the first k-half, 1 = before the second
             const half_t* Ps = Pb + (u_slab & 1) * PBUF;
             const int ky = u_tap / 3, kx = u_tap - 3 * ky;
             const int delta = ky * PW + kx;
@@ -721,6 +729,17 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
             }
             if (++u_tap == 9) { u_tap = 0; ++u_slab; }
         }
+    }
+    if (p.splits > 1) {                   // split-K: raw fp32 partials; splitk_reduce_kernel runs the epilogue
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int m = m0 + wm * 16 * MJ + j * 16 + l15;
+            if (m >= p.M) continue;
+            float* row = p.partial + ((long)split * p.M + m) * p.N + n0 + wn * 160 + g * 4;
+#pragma unroll
+            for (int i = 0; i < NF; ++i) *reinterpret_cast<f4*>(row + i * 16) = acc[i][j];
+        }
+        return;
     }
     if (p.epi_lds) {
         __syncthreads();
@@ -801,7 +820,7 @@ static int uv_pick_splits(long ntiles, int nk, long slots, int min_ktps, int max
 // LDS-patch 3x3 conv (conv_patch_kernel): whole image rows per tile, 16-pixel fragments inside one image row, patch <= 512 pixels
 static bool uv_conv_patch_eligible(const GemmParams& p, int bmb) {
     return p.W32 && p.taps == 9 && p.stride == 1 && p.C1 % 32 == 0 && p.C2 % 32 == 0 && (p.C1 + p.C2) % 64 == 0 && p.N % 320 == 0 && p.Wo % 16 == 0 &&
-           bmb % p.Wo == 0 && p.M % bmb == 0 && bmb / p.Wo <= p.Ho && (bmb / p.Wo + 3) * (p.Wo + 2) <= 512 && !p.geglu;
+           bmb % p.Wo == 0 && bmb / p.Wo <= p.Ho && (bmb / p.Wo + 3) * (p.Wo + 2) <= 512 && !p.geglu;
 }
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
@@ -834,13 +853,14 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         static const int splitk_big = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
         if (splitk_big && !nobig && !p.geglu && p.N % 320 == 0 && nblk < bigmin && nblk >= 8 && p.K >= 128 * 64) {   // fp32 partials cost ~35 us: long reductions only
             const int nk = (p.K + 63) / 64;
-            const int sp = uv_pick_splits(nblk, nk, uv_num_cus(), 24, 8, 2.2, (double)p.M * p.N * 4.0);
-            if (sp >= 2 && nblk * sp >= 128 && (size_t)sp * p.M * p.N * sizeof(float) <= UV_SPLITK_WS_BYTES) bsplits = sp;
+            int sp = uv_pick_splits(nblk, nk, uv_num_cus(), 24, 8, 2.2, (double)p.M * p.N * 4.0);
+            while (sp >= 2 && (size_t)sp * p.M * p.N * sizeof(float) > UV_SPLITK_WS_BYTES) --sp;     // what the partial workspace holds
+            if (sp >= 2 && nblk * sp >= 128) bsplits = sp;
         }
         static const int patch_env = getenv("UNIVST_CONV_PATCH") ? atoi(getenv("UNIVST_CONV_PATCH")) : 1;
-        const bool use_patch = patch_env && mode == 1 && bsplits == 1 && nblk >= bigmin && uv_conv_patch_eligible(p, use192 ? 192 : 256);
+        const bool use_patch = patch_env && mode == 1 && (nblk >= bigmin || bsplits > 1) && uv_conv_patch_eligible(p, use192 ? 192 : 256);
         UV_REQUIRE(p.W || use_patch, "conv: only the [Cin/32][9][32] weight copy was given but the problem is not eligible for the LDS-patch kernel "
-                   "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles)");
+                   "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles or a reduction long enough for split-K)");
         if (!nobig && p.N % 320 == 0 && (nblk >= bigmin || bsplits > 1) && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
             uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K,
                           2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
@@ -864,6 +884,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             if (bsplits > 1) {
                 const int nk = (p.K + 63) / 64;
                 q.ktps = (nk + bsplits - 1) / bsplits;
+                if (use_patch) q.ktps = (q.ktps + 8) / 9 * 9;      // a split starts at a 64-channel slab pair (9 k tiles)
                 q.splits = (nk + q.ktps - 1) / q.ktps;
                 const size_t need = (size_t)q.splits * p.M * p.N * sizeof(float);
                 if (!(q.partial && q.partial_bytes >= need)) {
@@ -879,6 +900,10 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             if (use_patch) {          // 3x3 / stride 1 on whole image rows: input patch in LDS, k order [Cin/32][9][32] (p.W32)
                 if (use192) hipLaunchKernelGGL((conv_patch_kernel<3>), bgrid, dim3(512), 0, stream, q);
                 else hipLaunchKernelGGL((conv_patch_kernel<4>), bgrid, dim3(512), 0, stream, q);
+                if (q.splits > 1) {
+                    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)p.M * (p.N / 4) + 255) / 256)), dim3(256), 0, stream, q);
+                    if (own_ws) UV_HIP(hipFreeAsync(q.partial, stream));
+                }
                 uv_prof_end(stream);
                 UV_LAUNCH_CHECK();
                 return UV_OK;
