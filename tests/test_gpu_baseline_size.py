@@ -151,6 +151,51 @@ def test_f16_fifty_step_transfer_vs_oracle_on_device(sd15, tag):
         assert torch.isfinite(got[i].float()).all() and vals[f"i{i}"] >= 40.0, vals
 
 
+def test_f16_fifty_step_easy_inversion_vs_oracle_on_device(sd15):
+    """BASELINE config 2 (and the producer of config 3's inputs): the 50-step single-branch Easy-Inv inversion
+    (inversion_tools/ddim_inversion.py:116-167) at 16x512x512 with the t = 301 feature dump, native engine vs the oracle loop
+    (fp32, device).  PSNR >= 40 dB on ddim_latents_k for k in {1,12,13,25,50}; the dumped up_blocks[2] features (the input of mask
+    propagation) within 5e-3 relative RMS."""
+    from univst_amd import engine
+    from univst_amd.schedulers import DDIMScheduler
+    unet, sd = sd15
+    cfg = unet_ref.SD15_CONFIG
+    F_, h, w, n = 16, 64, 64, 50
+    z0 = (0.8 * si.content_latent(0, F_, h, w)).half()
+    text = si.text_embedding(768).half()
+    pipe = types.SimpleNamespace(unet=unet)
+    sched = DDIMScheduler()
+    sched.set_timesteps(n)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        t0 = time.time()
+        got = engine.inversion_loop(pipe, sched, z0.cuda(), text.cuda(), n, True, ft_indices=[2], ft_timesteps=[301], ft_path=td)
+        torch.cuda.synchronize()
+        t_native = time.time() - t0
+        feat = torch.load(os.path.join(td, "inversion_feature_map_2_block_301_step.pt"))
+    osch = pipeline_ref.DDIMSchedule()
+    osch.set_timesteps(n)
+    ctx = text.float().cuda()
+    dump = {}
+
+    def eps_fn(z, t, i):
+        e, f = unet_ref.unet_forward(sd, cfg, z, int(t), ctx, None, ft_indices=[2] if int(t) == 301 else None, exact_temporal=False)
+        if f:
+            dump["feat"] = f[2]
+        return e
+    t0 = time.time()
+    with torch.no_grad():
+        ref = pipeline_ref.ddim_inversion_loop(eps_fn, osch, z0.float().cuda(), n, True)
+    torch.cuda.synchronize()
+    t_oracle = time.time() - t0
+    vals = {f"k{k}": psnr(got[k], ref[k]) for k in (1, 12, 13, 25, 50)}
+    mx, rms = errs(feat, dump["feat"])
+    record("inversion50_easy", dict(psnr_db=vals, feature_dump=dict(max_rel=mx, rms_rel=rms), native_s=t_native, oracle_fp32_device_s=t_oracle))
+    assert tuple(feat.shape) == (F_, 64, 64, 640) and feat.dtype == torch.float16
+    assert all(v >= 40.0 for v in vals.values()), vals
+    assert rms < 5e-3, (mx, rms)
+
+
 def test_mask_propagation_bit_exact_full_size():
     """mask indices bit-exact at the BASELINE size: 16 x 64x64 x 640 features (the up_blocks[2] dump), a multi-valued
     anti-aliased 512^2 first mask (256 one-hot classes), 512^2 outputs — native kernels vs oracle/maskprop_ref on the CPU,

@@ -47,5 +47,14 @@ def conv_ti(Ci, Co, H, imgs=48, C2=0, tag=""):
     fl = 2.0 * imgs * H * H * Co * 9 * (Ci + C2)
     print(f"conv3x3 TAP-INNER {Ci}+{C2}->{Co} @{H}x{H} {tag}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF")
 
+def conv_patch(Ci, Co, H, imgs=48, C2=0, tag=""):
+    x = torch.randn(imgs, H, H, Ci, device="cuda", dtype=torch.float16)
+    x2 = torch.randn(imgs, H, H, C2, device="cuda", dtype=torch.float16) if C2 else None
+    w = torch.randn(Co, (Ci + C2) // 32, 9, 32, device="cuda", dtype=torch.float16) * 0.02
+    b = torch.randn(Co, device="cuda", dtype=torch.float16)
+    ms = timeit(lambda: _native.conv3x3_patch(x, w, bias=b, x2=x2))
+    fl = 2.0 * imgs * H * H * Co * 9 * (Ci + C2)
+    print(f"conv3x3 LDS-PATCH {Ci}+{C2}->{Co} @{H}x{H} {tag}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF")
+
 if __name__ == "__main__":
     conv_ti(320, 320, 64); conv_ti(640, 320, 64, C2=320); conv_ti(640, 640, 32); conv_ti(1280, 1280, 16); conv_ti(1280, 1280, 8); conv_ti(1280, 1280, 8, C2=1280)

@@ -1,8 +1,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.bench_gemm import lin, conv_ti
+from tools.bench_gemm import lin, conv_ti, conv_patch
 which = sys.argv[1] if len(sys.argv) > 1 else "ff1"
 if which == "ff1": lin(196608, 2560, 320, geglu=True, tag="L0 ff1")
 elif which == "proj": lin(196608, 320, 320, res=True, tag="L0 proj")
 elif which == "qkv": lin(196608, 960, 320, tag="L0 qkv")
 elif which == "conv": conv_ti(320, 320, 64)
+elif which == "convp": conv_patch(320, 320, 64)

@@ -5,15 +5,22 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-2}
 O=$R/gpurun_out/profiles_new
 rm -rf $O && mkdir -p $O/raw
 cd $R
-python bench.py > $O/round1_bench_n1.json 2> $O/raw/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats -- python bench.py --no-cpu-baseline --no-skip-dead-branches-leg > $O/round1_bench_under_rocprof.json 2> $O/raw/stats.err
+python bench.py > $O/round${ROUND}_bench_n1.json 2> $O/raw/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats -- python bench.py --no-cpu-baseline --no-skip-dead-branches-leg > $O/round${ROUND}_bench_under_rocprof.json 2> $O/raw/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/raw/fetch -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/raw/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/raw/write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/raw/write.log 2>&1
-bash tools/pmc_attn.sh $O/raw/attn > $O/round1_pmc_attn_d40_sq.txt 2>&1
-bash tools/pmc_gemm.sh $O/raw/gemm 2>&1 | grep -E "^SQ_" > $O/round1_pmc_conv_tile_sq.txt
-python tools/summarize_profiles.py $O
+bash tools/pmc_attn.sh $O/raw/attn > $O/round${ROUND}_pmc_attn_d40_sq.txt 2>&1
+bash tools/pmc_gemm.sh $O/raw/gemm convp 2>&1 | grep -E "^SQ_" > $O/round${ROUND}_pmc_conv_patch_sq.txt
+for w in inversion maskprop warp; do python bench.py --workload $w --no-cpu-baseline > $O/round${ROUND}_bench_$w.json 2>> $O/raw/bench.err; done
+python bench.py --frames 32 --emulate-rank 0/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank0of8.json 2>> $O/raw/bench.err
+python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8.json 2>> $O/raw/bench.err
+python bench.py --frames 32 --emulate-rank 7/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank7of8.json 2>> $O/raw/bench.err
+python bench.py --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8.json 2>> $O/raw/bench.err
+python bench.py --frames 32 --no-cpu-baseline --no-skip-dead-branches-leg > $O/round${ROUND}_bench_f32_n1.json 2>> $O/raw/bench.err
+ROUND=$ROUND python tools/summarize_profiles.py $O
 rm -rf $O/raw/stats/*/*_agent_info.csv
 ls -la $O

@@ -2,6 +2,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 O = sys.argv[1]
+RND = os.environ.get("ROUND", "2")
 
 def one(pattern):
     hits = glob.glob(os.path.join(O, "raw", pattern), recursive=True)
@@ -10,7 +11,7 @@ def one(pattern):
 # 1. kernel stats summary (rocprofv3 --stats) -> round1_kernel_stats.csv
 ks = one("stats/**/*kernel_stats.csv")
 if ks:
-    shutil.copy(ks, os.path.join(O, "round1_kernel_stats.csv"))
+    shutil.copy(ks, os.path.join(O, f"round{RND}_kernel_stats.csv"))
 
 # 2. HBM traffic per launch per kernel from the two counter passes
 def per_kernel(pattern, counter):
@@ -37,18 +38,18 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE 
                    "FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024; WRITE_SIZE "
                    "and narrow/strided reads are uncalibrated, so treat the absolute as an upper-bound estimate.  Averages are per launch over "
                    "ALL launches of a kernel symbol (all layer shapes).",
-           "kernels": kern}, open(os.path.join(O, "round1_pmc_traffic.json"), "w"), indent=1)
+           "kernels": kern}, open(os.path.join(O, f"round{RND}_pmc_traffic.json"), "w"), indent=1)
 
 # 3. agreement between bench.py's HIP-event timing and rocprofv3 for the dominant kernel
 try:
-    b = json.loads(open(os.path.join(O, "round1_bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    b = json.loads(open(os.path.join(O, f"round{RND}_bench_under_rocprof.json")).read().strip().splitlines()[-1])
     dom = b["roofline"]["kernel"]
     base, targ = dom.split("<")[0], dom.split("<")[1].rstrip(">").replace(" ", "")
     rows = [r for r in csv.DictReader(open(ks)) if base in r["Name"] and targ in r["Name"].replace(" ", "")]
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
-    open(os.path.join(O, "round1_agreement.txt"), "w").write(
+    open(os.path.join(O, f"round{RND}_agreement.txt"), "w").write(
         f"dominant kernel class {dom}: bench.py HIP-event average launch {b['roofline']['avg_launch_ms']:.4f} ms vs rocprofv3 "
         f"average {tot_ns / calls / 1e6:.4f} ms ({calls} calls, {len(rows)} kernel symbol(s))\n")
-    print(open(os.path.join(O, "round1_agreement.txt")).read())
+    print(open(os.path.join(O, f"round{RND}_agreement.txt")).read())
 except Exception as e:
     print("agreement check failed:", repr(e))
