@@ -15,6 +15,7 @@ The default workload is the headline (BASELINE config 3 without the optional smo
 masks blended on steps 0..45).  --workload selects the other driver-timed lines (same JSON shape, own `roofline`):
   transfer_nomask   the same loop without masks
   inversion         BASELINE config 2: the single-branch DDIM inversion loop (one step = one single-branch UNet call + next_step)
+  inversion_pair    the content + style inversions of one job as one batch-2 trajectory (value = frames of BOTH clips / s)
   maskprop          point-matching mask propagation of a 16-frame clip (64x64x640 features, 256 classes, 512^2 masks); HBM-bound
   warp              one sliding-window smoothing pass over 16 x 512^2 frames (58 occlusion + remap + blend launches); HBM-bound
 """
@@ -44,7 +45,7 @@ def parse():
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
-    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "maskprop", "warp"])
+    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "inversion_pair", "maskprop", "warp"])
     ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
                                                              "(no extrapolation in F; ~2 min on 16 threads) instead of F=2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,7 +255,7 @@ def main():
     unet = synth.build_unet(device=dev, seed=33)
     pipe = Pipe(unet, DDIMScheduler())
     pipe.scheduler.set_timesteps(50)
-    if a.workload != "inversion":          # the inversion UNet is the stock one (run_content_inversion_sd.py never registers PnP)
+    if not a.workload.startswith("inversion"):          # the inversion UNet is the stock one (run_content_inversion_sd.py never registers PnP)
         pnp_utils.register_spatial_attention_pnp(pipe)
     masked = a.workload == "transfer"
     content, style, text3, mask = synth.synth_transfer_inputs(F=F_total, h=h, w=h, device=dev, with_mask=masked, mask_hw=8 * h)
@@ -266,19 +267,21 @@ def main():
         mask_m = mask_m.reshape(-1, h, h)[shard.f0:shard.f0 + shard.local].contiguous()
     shard.attach(unet, max_tokens=h * h)
     sharded = world > 1 or emu is not None
-    if a.workload == "inversion":
+    inv = a.workload.startswith("inversion")
+    pair = a.workload == "inversion_pair"
+    if inv:
         from univst_amd import engine
         assert not sharded, "--workload inversion: single GPU line (config 2)"
         pipe.unet = unet
-        text1 = text3[2:3].contiguous()
+        text1 = text3[2:3].contiguous() if not pair else text3[1:3].contiguous()
         ts = [int(t) for t in pipe.scheduler.timesteps.tolist()]
-        lat = content[0]
+        lat = content[0] if not pair else torch.cat([content[0], style[0]])
 
         def step(i, z):
             t = ts[len(ts) - (i % 50) - 1]
             eps = unet(z, t, encoder_hidden_states=text1).sample
             return engine.next_step(eps, t, z, pipe.scheduler)
-    else:
+    if not inv:
         lat = shard.latent_adain(content[50], style[50]) if sharded else pnp_utils.latent_adain(content[50], style[50])
         step = shard.make_step_fn(pipe, content, style, text3, mask_m) if sharded else make_step_fn(pipe, content, style, text3, mask_m)
 
@@ -302,16 +305,17 @@ def main():
         dt = tmax.item()
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
     ms_per_step = dt / a.steps * 1e3
-    value = F_total / (50 * ms_per_step / 1e3)
+    value = F_total * (2 if a.workload == "inversion_pair" else 1) / (50 * ms_per_step / 1e3)
 
     out = {
-        "metric": ("inverted frames/sec, SD-v1.5 16x512x512 @50 DDIM inversion steps" if a.workload == "inversion" else
+        "metric": ("inverted frames/sec, SD-v1.5 16x512x512 @50 DDIM inversion steps" if inv else
                    "stylized frames/sec, SD-v1.5 16x512x512 @50 DDIM steps"), "value": round(value, 4), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": (f"sd15_unet_single_branch_ddim_inversion_{F_total}x{h * 8}x{h * 8}_50ddim" if a.workload == "inversion" else
+        "config": {"workload": ((f"sd15_unet_content_plus_style_ddim_inversion_batch2_{F_total}x{h * 8}x{h * 8}_50ddim" if pair else
+                                 f"sd15_unet_single_branch_ddim_inversion_{F_total}x{h * 8}x{h * 8}_50ddim") if inv else
                                 f"sd15_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
-                   "latent": [1, 4, F_total, h, h], "branches": 1 if a.workload == "inversion" else 3,
+                   "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
                    "weights": "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16"},
     }
@@ -357,7 +361,7 @@ def main():
                 out["roofline"]["traffic_source"] = f"profiles/{cands[-1]} (rocprofv3 PMC, gfx950-corrected, bytes/launch)"
         except Exception:
             pass
-        if a.workload != "inversion":
+        if not inv:
             Fl = shard.local
             # duplicate key sources are merged exactly (frame 0: {0,0,0} -> one read with log2(3) added; frame 1: {0,1,0} / {0,0}):
             # executed attention work / algorithmic work, stock and PnP layers, for this rank's frames
@@ -370,7 +374,7 @@ def main():
         out["config"]["algorithmic_tflop_per_step_executed"] = round(tot_flops / 1e12, 2)
         out["roofline"]["whole_step_tflops"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12, 1)
 
-    if not a.no_skip_dead_branches_leg and world == 1 and emu is None and a.steps >= 50 and a.workload != "inversion":
+    if not a.no_skip_dead_branches_leg and world == 1 and emu is None and a.steps >= 50 and not inv:
         from univst_amd import engine
         sync()
         t0 = time.perf_counter()
@@ -383,7 +387,7 @@ def main():
 
     if rank == 0:
         if not a.no_cpu_baseline and world == 1 and emu is None:
-            out["cpu_baseline"] = cpu_baseline(F_total, unet, full=a.full_cpu, single_branch=a.workload == "inversion")
+            out["cpu_baseline"] = cpu_baseline(F_total, unet, full=a.full_cpu, single_branch=inv)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -48,7 +48,7 @@ def psnr(got, ref):
     got, ref = got.float(), ref.float().to(got.device)
     mse = (got - ref).pow(2).mean().item()
     peak = (ref.max() - ref.min()).item()
-    return 10 * math.log10(peak * peak / mse)
+    return float("inf") if mse == 0 else 10 * math.log10(peak * peak / mse)
 
 
 @pytest.fixture(scope="module")

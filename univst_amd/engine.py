@@ -125,13 +125,25 @@ def _unet_single_branch(unet, latents, t, text1):
     return unet(latents, t, encoder_hidden_states=text1).sample
 
 
-def inversion_loop(pipe, sched, latent: torch.Tensor, text1: torch.Tensor, num_inv_steps: int, easy_inv: bool,
+def inversion_loop(pipe, sched, latent: torch.Tensor, text1: torch.Tensor, num_inv_steps: int, easy_inv,
                    ft_indices=None, ft_timesteps=None, ft_path=None, on_latent: Optional[Callable] = None) -> List[torch.Tensor]:
     """ddim_inversion.py:87-167 (``ddim_loop`` / ``ddim_loop_plus``), device-resident.  ``on_latent(k, z)`` is
-    called for k = 0..num_inv_steps (the reference's torch.save points)."""
+    called for k = 0..num_inv_steps (the reference's torch.save points).
+
+    ``latent`` may carry several independent trajectories along the batch axis ([B,4,F,h,w], B <= 8) with ``easy_inv`` a
+    per-trajectory list: the content (Easy-Inv) and the style (plain DDIM) inversions of one job then share every UNet call
+    — the same arithmetic per trajectory (GroupNorm / attention never mix batch elements), twice the rows per launch, which
+    is what the single-branch shapes lack.  The feature dump is taken from trajectory 0, as in the reference
+    (unet_3d_condition.py:430-436 dumps sample[0])."""
     dev = latent.device
     latent = _dev16(latent, dev)
+    B = latent.shape[0]
+    easy = list(easy_inv) if isinstance(easy_inv, (list, tuple)) else [bool(easy_inv)] * B
+    if len(easy) != B:
+        raise ValueError(f"easy_inv has {len(easy)} entries for a batch of {B} trajectories")
     text1 = _dev16(text1, dev)
+    if text1.shape[0] == 1 and B > 1:
+        text1 = text1.expand(B, -1, -1).contiguous()
     all_latent = [latent]
     if on_latent:
         on_latent(0, latent)
@@ -141,8 +153,12 @@ def inversion_loop(pipe, sched, latent: torch.Tensor, text1: torch.Tensor, num_i
         t = timesteps[len(timesteps) - i - 1]
         eps = pipe.unet(latent, t, encoder_hidden_states=text1, ft_indices=ft_indices, ft_timesteps=ft_timesteps,
                         ft_path=ft_path)["sample"]
-        if easy_inv and (0.05 + 0.2) * 50 > i > 0.05 * 50 and i > 0:
-            latent = _native.axpby(latent, last_latent, 0.5, 0.5)      # Easy-Inv averaging, AFTER eps
+        if any(easy) and (0.05 + 0.2) * 50 > i > 0.05 * 50 and i > 0:
+            if all(easy):
+                latent = _native.axpby(latent, last_latent, 0.5, 0.5)      # Easy-Inv averaging, AFTER eps
+            else:
+                latent = torch.cat([_native.axpby(latent[b:b + 1].contiguous(), last_latent[b:b + 1].contiguous(), 0.5, 0.5) if easy[b]
+                                    else latent[b:b + 1] for b in range(B)])
         last_latent = latent
         latent = next_step(eps, t, latent, sched)
         if on_latent:

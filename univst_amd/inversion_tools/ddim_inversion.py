@@ -106,3 +106,23 @@ def get_noise_pred_single(pipeline, latents, t, context, ft_indices=None, ft_tim
     """ddim_inversion.py:207-212"""
     return pipeline.unet(latents, t, encoder_hidden_states=context, ft_indices=ft_indices, ft_timesteps=ft_timesteps,
                          ft_path=ft_path)["sample"]
+
+
+@torch.no_grad()
+def paired_ddim_inversion(pipeline, ddim_scheduler, content_latent, style_latent, num_inv_steps, prompt="", content_inversion_path=None,
+                          style_inversion_path=None, ft_indices=None, ft_timesteps=None, ft_path=None, content_is_opt=True, style_is_opt=False):
+    """Not in the reference (it runs the two inversions as two scripts, scripts/start_sd.sh): the content and the style inversion
+    of one job as ONE batch-2 trajectory, so every UNet call works on twice the rows (the single-branch shapes leave the 256-CU
+    chip half empty at the 32x32 / 16x16 levels).  Per trajectory the arithmetic is that of ddim_inversion(); the files written are
+    the same ``ddim_latents_k.pt`` in the two folders and the same feature dump (content trajectory).  Returns (content, style)
+    lists of 51 latents."""
+    cond = init_prompt(pipeline, prompt).chunk(2)[1]
+    z = torch.cat([content_latent, style_latent]).cuda()
+
+    def save(k, zz):
+        for path, b in ((content_inversion_path, 0), (style_inversion_path, 1)):
+            if path is not None:
+                torch.save(zz[b:b + 1].detach().clone(), os.path.join(path, f"ddim_latents_{k}.pt"))
+    traj = engine.inversion_loop(pipeline, ddim_scheduler, z, cond, num_inv_steps, [content_is_opt, style_is_opt], ft_indices, ft_timesteps,
+                                 ft_path, save)
+    return [t[0:1] for t in traj], [t[1:2] for t in traj]
