@@ -221,10 +221,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = min(local, torch.cuda.device_count() - 1)      # (bring-up: several ranks may share one GPU with --backend gloo)
         torch.cuda.set_device(local)
+        import datetime
+        tmo = datetime.timedelta(seconds=300)        # a rank that died leaves its peers in a collective: fail in minutes, not in NCCL's default 10
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=tmo)
         else:
-            dist.init_process_group(a.backend)
+            dist.init_process_group(a.backend, timeout=tmo)
     else:
         dist = None
         torch.cuda.set_device(0)

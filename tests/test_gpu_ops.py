@@ -228,8 +228,24 @@ def test_conv3x3_lds_patch_split_k_and_tail(nat, C1, C2, Co, H, imgs):
     close(got, nhwc(ref))
 
 
+@pytest.mark.parametrize("C1,C2,Co,H,imgs", [(1280, 0, 1280, 8, 48),      # the 8x8 level: 4 (256-row) whole images per tile, split-K over slab pairs
+                                              (1280, 1280, 1280, 8, 48),   # up-path concat at 8x8
+                                              (64, 0, 320, 8, 800)])       # 8x8 images without split-K (200 tiles): 3 separators per 192-row tile
+def test_conv3x3_lds_patch_small_images(nat, C1, C2, Co, H, imgs):
+    """image width 8 (two image rows per 16-pixel MFMA fragment) and tiles that hold several whole images: one zero row between
+    every two images of the patch."""
+    x1 = rnd(imgs, C1, H, H, seed=1)
+    x2 = rnd(imgs, C2, H, H, seed=2) if C2 else None
+    w = rnd(Co, C1 + C2, 3, 3, seed=3, scale=1 / math.sqrt(9 * (C1 + C2)))
+    b, res = rnd(Co, seed=4), rnd(imgs, Co, H, H, seed=6)
+    xin = torch.cat([x1, x2], 1).float() if C2 else x1.float()
+    ref = F.conv2d(xin, w.float(), b.float(), padding=1) + res.float()
+    got = nat.conv3x3_patch(nhwc(x1), conv_w_t32(w), bias=b, x2=None if x2 is None else nhwc(x2), residual=nhwc(res))
+    close(got, nhwc(ref))
+
+
 def test_conv3x3_lds_patch_rejects_ineligible(nat):
-    x = rnd(6, 32, 8, 8, seed=1)
+    x = rnd(6, 32, 4, 4, seed=1)
     w = rnd(320, 32, 3, 3, seed=2)
     with pytest.raises(RuntimeError, match="not eligible"):
         nat.conv3x3_patch(nhwc(x), conv_w_t32(w))

@@ -599,8 +599,9 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
 // Patch image: pixel-major, 64 B per pixel (32 channels), 16-byte chunk c of pixel p stored at chunk c ^ (((p >> 2) & 1) << 1):
 // conflict-free for the ds_read_b128 lane groups at ANY pixel shift (brute-forced against MI355X_MICROARCH.md §LDS).
 // The swizzle is applied to the per-lane SOURCE address (the DMA writes lane-linear) and to the fragment reads.
-// A tile may straddle two images (192-row tiles do): one zero row is inserted between them, which serves as the bottom
-// padding of the upper image and the top padding of the lower one.
+// A tile may straddle image boundaries (192-row tiles do; at the 8x8 level a tile holds three or four whole images): ONE zero
+// row is inserted between two images, which serves as the bottom padding of the upper image and the top padding of the lower
+// one.  Image widths below 16 are fine as long as they divide 16 (a 16-pixel MFMA fragment then covers whole image rows).
 template <int MJ>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     constexpr int NF = 10, BMB = 64 * MJ, BNB = 320, LDSH = 64;
@@ -626,10 +627,12 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     const int rows_total = p.M / Wd;                         // image rows in the stack of all images
     const int R = BMB / Wd;
     const int gr0 = m0 / Wd;                                 // first image row of the tile in the stack of all images
-    const int bnd = (gr0 / Himg + 1) * Himg;                 // next image boundary
-    const bool straddle = bnd < gr0 + R;
-    const int pz = straddle ? bnd - gr0 + 1 : (1 << 30);     // patch row that is the inserted zero row
-    const int nprow = R + 2 + (straddle ? 1 : 0);
+    // patch rows: [row above the tile | tile rows, with one zero row wherever two images meet | row below the tile].  In the
+    // sequence "image rows + one separator per image" (period Himg + 1) the tile's first row sits at position r0, so patch row
+    // py is sequence element py - 1 + r0; elements at position Himg of a period (and the one before the first image) are zero rows.
+    const int r0 = gr0 % Himg;
+    const int nsep = (gr0 + R - 1) / Himg - gr0 / Himg;      // image boundaries strictly inside the tile
+    const int nprow = R + 2 + nsep;
     const int npieces = nprow * PW * 4;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const half_t* zp = uv_zero_page;
@@ -645,10 +648,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         const int q = i * 512 + tid;
         const int pp = q >> 2, cst = q & 3;
         const int py = pp / PW, px = pp - py * PW;
-        const int gr = gr0 - 1 + py - (py > pz ? 1 : 0);
-        bool ok = q < npieces && px >= 1 && px <= Wd && py != pz && gr < rows_total;
-        if (py == 0 && gr0 % Himg == 0) ok = false;                      // top padding of an image
-        if (py == nprow - 1 && (gr0 + R) % Himg == 0) ok = false;        // bottom padding
+        const int sq = py - 1 + r0;                                      // element of the rows-plus-separators sequence
+        const int seg = sq >= 0 ? sq / (Himg + 1) : 0, pos = sq >= 0 ? sq - seg * (Himg + 1) : Himg;
+        const int gr = gr0 - r0 + seg * Himg + pos;
+        const bool ok = q < npieces && px >= 1 && px <= Wd && pos != Himg && gr < rows_total;      // pos == Himg: zero row (padding)
         const int img = gr / Himg, yy = gr - img * Himg;                 // fused nearest x2 upsample (p.up): source pixel = (y >> 1, x >> 1)
         ppix[i] = ok ? (img * p.Hs + (yy >> p.up)) * p.Ws + ((px - 1) >> p.up) : -1;
         pch[i] = (cst ^ (((pp >> 2) & 1) << 1)) * 8;
@@ -680,9 +683,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     int pbase[MJ];
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
-        const int ml = wm * 16 * MJ + j * 16;
+        const int ml = wm * 16 * MJ + j * 16 + l15;          // this lane's output pixel in the tile
         const int ry = ml / Wd, rx = ml - ry * Wd;
-        pbase[j] = (ry + ((straddle && gr0 + ry >= bnd) ? 1 : 0)) * PW + rx + l15;
+        const int seps = (gr0 + ry) / Himg - gr0 / Himg;     // zero rows inserted above it
+        pbase[j] = (ry + seps) * PW + rx;
     }
 
     f4 acc[NF][MJ];
@@ -819,8 +823,8 @@ static int uv_pick_splits(long ntiles, int nk, long slots, int min_ktps, int max
 
 // LDS-patch 3x3 conv (conv_patch_kernel): whole image rows per tile, 16-pixel fragments inside one image row, patch <= 512 pixels
 static bool uv_conv_patch_eligible(const GemmParams& p, int bmb) {
-    return p.W32 && p.taps == 9 && p.stride == 1 && p.C1 % 32 == 0 && p.C2 % 32 == 0 && (p.C1 + p.C2) % 64 == 0 && p.N % 320 == 0 && p.Wo % 16 == 0 &&
-           bmb % p.Wo == 0 && bmb / p.Wo <= p.Ho && (bmb / p.Wo + 3) * (p.Wo + 2) <= 512 && !p.geglu;
+    return p.W32 && p.taps == 9 && p.stride == 1 && p.C1 % 32 == 0 && p.C2 % 32 == 0 && (p.C1 + p.C2) % 64 == 0 && p.N % 320 == 0 && (p.Wo % 16 == 0 || 16 % p.Wo == 0) &&
+           bmb % p.Wo == 0 && (bmb / p.Wo + 2 + bmb / p.Wo / p.Ho + 1) * (p.Wo + 2) <= 512 && !p.geglu;
 }
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {

@@ -51,7 +51,7 @@ struct AttnParams {
 };
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
-constexpr size_t UV_SPLITK_WS_BYTES = 48u << 20;   // enough for 512 blocks of 128 x 160 fp32 partials
+constexpr size_t UV_SPLITK_WS_BYTES = 128u << 20;  // fp32 partials [splits][M][N]: 8 splits of the 8x8-level convs (3072 x 1280)
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);
 struct UvGnComm {      // cross-rank reduction hook of the 5-D GroupNorm (frame sharding)
