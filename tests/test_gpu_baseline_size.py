@@ -155,10 +155,15 @@ def test_f16_fifty_step_easy_inversion_vs_oracle_on_device(sd15):
     """BASELINE config 2 (and the producer of config 3's inputs): the 50-step single-branch Easy-Inv inversion
     (inversion_tools/ddim_inversion.py:116-167) at 16x512x512 with the t = 301 feature dump, native engine vs the oracle loop
     (fp32, device).  PSNR >= 40 dB on ddim_latents_k for k in {1,12,13,25,50}; the dumped up_blocks[2] features (the input of mask
-    propagation) within 5e-3 relative RMS."""
+    propagation) within 5e-3 relative RMS of the oracle forward at the same latent, and within 5e-2 of the oracle loop's own dump
+    (15 steps of drift through a random-weight UNet)."""
     from univst_amd import engine
     from univst_amd.schedulers import DDIMScheduler
+    from univst_amd.backbones.video_diffusion_sd.pnp_utils import PNP_LAYERS
     unet, sd = sd15
+    for r, bs in PNP_LAYERS.items():       # the shared UNet may carry the PnP registration of an earlier test: inversion runs the stock layers
+        for b in bs:
+            unet.up_blocks[r].attentions[b].transformer_blocks[0].attn1.__dict__.pop("_univst_native_pnp", None)
     cfg = unet_ref.SD15_CONFIG
     F_, h, w, n = 16, 64, 64, 50
     z0 = (0.8 * si.content_latent(0, F_, h, w)).half()
@@ -189,11 +194,15 @@ def test_f16_fifty_step_easy_inversion_vs_oracle_on_device(sd15):
     torch.cuda.synchronize()
     t_oracle = time.time() - t0
     vals = {f"k{k}": psnr(got[k], ref[k]) for k in (1, 12, 13, 25, 50)}
-    mx, rms = errs(feat, dump["feat"])
-    record("inversion50_easy", dict(psnr_db=vals, feature_dump=dict(max_rel=mx, rms_rel=rms), native_s=t_native, oracle_fp32_device_s=t_oracle))
+    mx, rms = errs(feat, dump["feat"])                  # includes 15 steps of trajectory drift, amplified by the (random-weight) UNet
+    with torch.no_grad():                               # the dump itself: oracle forward at the NATIVE loop's own latent of that step (t = 301 is i = 15)
+        _, f_same = unet_ref.unet_forward(sd, cfg, got[15].float(), 301, ctx, None, ft_indices=[2], exact_temporal=False)
+    mx1, rms1 = errs(feat, f_same[2])
+    record("inversion50_easy", dict(psnr_db=vals, feature_dump_along_trajectories=dict(max_rel=mx, rms_rel=rms),
+                                    feature_dump_same_input=dict(max_rel=mx1, rms_rel=rms1), native_s=t_native, oracle_fp32_device_s=t_oracle))
     assert tuple(feat.shape) == (F_, 64, 64, 640) and feat.dtype == torch.float16
     assert all(v >= 40.0 for v in vals.values()), vals
-    assert rms < 5e-3, (mx, rms)
+    assert rms1 < 5e-3 and rms < 5e-2, (mx1, rms1, mx, rms)
 
 
 def test_mask_propagation_bit_exact_full_size():
