@@ -358,8 +358,9 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["kernels"]
             key = dom.replace(" ", "")
             hit = [v for k, v in pm.items() if key.split("<")[0] in k and key.split("<")[1].rstrip(">") in k.replace(" ", "")]
-            if hit and world == 1:
-                out["roofline"]["traffic"] = hit[0]["hbm_bytes_per_launch_corrected"]
+            if hit and world == 1:      # a class may span several symbols (the 256- and 192-row tile): launch-weighted mean
+                nl = sum(v["launches_sampled"] for v in hit)
+                out["roofline"]["traffic"] = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] for v in hit) / max(nl, 1))
                 out["roofline"]["traffic_source"] = f"profiles/{cands[-1]} (rocprofv3 PMC, gfx950-corrected, bytes/launch)"
         except Exception:
             pass
