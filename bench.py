@@ -46,6 +46,8 @@ def parse():
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
     ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "inversion_pair", "maskprop", "warp"])
+    ap.add_argument("--model", default="sd15", choices=["sd15", "sd21"], help="UNet configuration: SD-v1.5 (headline) or the SD-v2.1 layout "
+                                                                            "(Linear projections, head_dim 64, 1024-wide text states; SURVEY §8f-3)")
     ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
                                                              "(no extrapolation in F; ~2 min on 16 threads) instead of F=2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -254,13 +256,13 @@ def main():
         shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew))
     else:
         shard = FrameShard(rank, world, F_total)
-    unet = synth.build_unet(device=dev, seed=33)
+    unet = synth.build_unet(config=synth.SD21_UNET_CONFIG if a.model == "sd21" else None, device=dev, seed=33)
     pipe = Pipe(unet, DDIMScheduler())
     pipe.scheduler.set_timesteps(50)
     if not a.workload.startswith("inversion"):          # the inversion UNet is the stock one (run_content_inversion_sd.py never registers PnP)
         pnp_utils.register_spatial_attention_pnp(pipe)
     masked = a.workload == "transfer"
-    content, style, text3, mask = synth.synth_transfer_inputs(F=F_total, h=h, w=h, device=dev, with_mask=masked, mask_hw=8 * h)
+    content, style, text3, mask = synth.synth_transfer_inputs(F=F_total, h=h, w=h, D=1024 if a.model == "sd21" else 768, device=dev, with_mask=masked, mask_hw=8 * h)
     content = [shard.slice_frames(t) for t in content]
     style = [shard.slice_frames(t) for t in style]
     mask_m = None
@@ -311,15 +313,16 @@ def main():
 
     out = {
         "metric": ("inverted frames/sec, SD-v1.5 16x512x512 @50 DDIM inversion steps" if inv else
-                   "stylized frames/sec, SD-v1.5 16x512x512 @50 DDIM steps"), "value": round(value, 4), "unit": "frames/s",
+                   "stylized frames/sec, SD-v1.5 16x512x512 @50 DDIM steps").replace("SD-v1.5", "SD-v2.1 layout" if a.model == "sd21" else "SD-v1.5"), "value": round(value, 4), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": ((f"sd15_unet_content_plus_style_ddim_inversion_batch2_{F_total}x{h * 8}x{h * 8}_50ddim" if pair else
                                  f"sd15_unet_single_branch_ddim_inversion_{F_total}x{h * 8}x{h * 8}_50ddim") if inv else
-                                f"sd15_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
+                                f"{a.model}_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
-                   "weights": "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16"},
+                   "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else
+                               "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16")},
     }
 
     if rank == 0 and not a.no_profile:
@@ -389,7 +392,7 @@ def main():
                                                           "same latents up to fp32 summation order (tests: >= 60 dB), 102 instead of 150 branch-steps; NOT the headline value")
 
     if rank == 0:
-        if not a.no_cpu_baseline and world == 1 and emu is None:
+        if not a.no_cpu_baseline and world == 1 and emu is None and a.model == "sd15":
             out["cpu_baseline"] = cpu_baseline(F_total, unet, full=a.full_cpu, single_branch=inv)
         print(json.dumps(out))
     if dist is not None:

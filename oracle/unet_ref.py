@@ -38,6 +38,11 @@ TINY_CONFIG = dict(SD15_CONFIG, block_out_channels=(32, 64, 64, 64), layers_per_
 # SD-v2.x shaped tiny config: Linear proj_in/out, per-level head counts (head_dim 16/32), wider text dim
 TINY_SD2_CONFIG = dict(TINY_CONFIG, use_linear_projection=True, attention_head_dim=(2, 2, 4, 4), cross_attention_dim=64)
 
+# SD-v2.1 (run_content_inversion_sd.py:78 of the reference keeps it as the commented default): same channel widths, Linear
+# proj_in / proj_out, head_dim 64 => 5 / 10 / 20 / 20 heads (config.json's attention_head_dim is the head COUNT per level), 1024-wide
+# OpenCLIP text states
+SD21_CONFIG = dict(SD15_CONFIG, use_linear_projection=True, attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024)
+
 # pnp_utils.py:104-111 — the 8 injected attn1 layers: {up_block: [attention indices]}
 PNP_LAYERS = {1: [1, 2], 2: [0, 1, 2], 3: [0, 1, 2]}
 

@@ -205,6 +205,36 @@ def test_f16_fifty_step_easy_inversion_vs_oracle_on_device(sd15):
     assert rms1 < 5e-3 and rms < 5e-2, (mx1, rms1, mx, rms)
 
 
+def test_sd21_widths_step_vs_oracle_on_device():
+    """SURVEY §8f-3 at the real size: the SD-v2.1 layout (Linear proj_in / proj_out, head_dim 64 at every level => 5/10/20/20
+    heads, 1024-wide text states) with SD widths, 64x64 latents, three branches, F = 4, inside and outside the PnP window, native
+    graph vs the oracle in fp32 on the device.  Same bound as the SD-v1.5 forward (max 5e-3, relative RMS 3e-3)."""
+    from univst_amd import synth
+    from univst_amd.backbones.video_diffusion_sd import pnp_utils
+    unet = synth.build_unet(config=synth.SD21_UNET_CONFIG, device="cuda", seed=9)
+    sd = {k: v.float() for k, v in unet.state_dict().items()}
+    cfg = unet_ref.SD21_CONFIG
+    unet_ref.SDPA_MAX_BATCH = 4
+    try:
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(3, 4, 4, 64, 64, generator=g).half().cuda()
+        ctx = torch.randn(1, 77, 1024, generator=g).half().cuda().expand(3, -1, -1).contiguous()
+        pipe = types.SimpleNamespace(unet=unet)
+        pnp_utils.register_spatial_attention_pnp(pipe)
+        out = {}
+        for idx, t in ((12, 741), (40, 181)):
+            pnp_utils.register_time(pipe, idx)
+            got = unet(x, t, encoder_hidden_states=ctx).sample
+            with torch.no_grad():
+                ref, _ = unet_ref.unet_forward(sd, cfg, x.float(), t, ctx.float(), pnp_idx=idx, exact_temporal=False)
+            mx, rms = errs(got, ref)
+            out[f"idx{idx}"] = dict(max_rel=mx, rms_rel=rms)
+            assert torch.isfinite(got.float()).all() and mx < 5e-3 and rms < 3e-3, (idx, mx, rms)
+        record("sd21_forward_f4", out)
+    finally:
+        unet_ref.SDPA_MAX_BATCH = None
+
+
 def test_mask_propagation_bit_exact_full_size():
     """mask indices bit-exact at the BASELINE size: 16 x 64x64 x 640 features (the up_blocks[2] dump), a multi-valued
     anti-aliased 512^2 first mask (256 one-hot classes), 512^2 outputs — native kernels vs oracle/maskprop_ref on the CPU,

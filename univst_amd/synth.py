@@ -11,6 +11,9 @@ SD15_UNET_CONFIG = dict(sample_size=64, in_channels=4, out_channels=4, block_out
                         norm_eps=1e-5)
 
 
+SD21_UNET_CONFIG = dict(SD15_UNET_CONFIG, use_linear_projection=True, attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024)
+
+
 def build_unet(config=None, device="cuda", dtype=torch.float16, seed=33):
     """UNetPseudo3DConditionModel with synthetic weights, materialised straight on ``device``."""
     from .backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel
