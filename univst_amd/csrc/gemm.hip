@@ -44,7 +44,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                 if (ng >= p.N) continue;
                 const int no = nb / 2 + (i / 2) * 16 + g * 4;
                 h4 o, bx = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-                if (p.bias) {
+                if (p.bias) {                               // (hoisting these 64-byte L1 hits out of the store loop measured -3 %)
                     bx = *reinterpret_cast<const h4*>(p.bias + nx);
                     bg = *reinterpret_cast<const h4*>(p.bias + ng);
                 }
@@ -58,6 +58,14 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
             }
         }
         return;
+    }
+    // The residual row is requested before the first STORE: hipcc may not move a load above an earlier store to Y (possible
+    // alias), so loads placed inside the store loop each wait out an HBM round trip in turn.
+    h4 hres[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        const int n = nb + i * 16 + g * 4;
+        hres[i] = (p.R && n + 3 < p.N) ? *reinterpret_cast<const h4*>(p.R + (long)m * p.ldr + n) : h4{0, 0, 0, 0};
     }
 #pragma unroll
     for (int i = 0; i < NF; ++i) {
@@ -78,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                 for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
             }
             if (p.R) {
-                h4 rv = *reinterpret_cast<const h4*>(p.R + (long)m * p.ldr + n);
+                const h4 rv = hres[i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
             }
@@ -124,6 +132,19 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
         __builtin_amdgcn_wave_barrier();
         const int mrow0 = mw + j * 16;
         if (!p.geglu) {
+            // residual rows of all five passes are requested BEFORE the first store: hipcc cannot move a load of R above an
+            // earlier store to Y (the two may alias for all it knows), so written pass by pass every residual load sat out a
+            // full HBM latency behind the previous pass's store — 20 serial round trips per wave, most of a K = 320 tile's time
+            h8 rres[5];
+            if (p.R) {
+#pragma unroll
+                for (int it = 0; it < 5; ++it) {
+                    const int id = it * 64 + lane;
+                    const int row = id / 20, c = (id - row * 20) * 8;
+                    const int m = mrow0 + row < p.M ? mrow0 + row : p.M - 1;
+                    rres[it] = *reinterpret_cast<const h8*>(p.R + (long)m * p.ldr + nb + c);
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
                 const int id = it * 64 + lane;
@@ -144,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
                 }
                 if (p.R) {
-                    const h8 rv = *reinterpret_cast<const h8*>(p.R + (long)m * p.ldr + n);
+                    const h8 rv = rres[it];
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
                 }
