@@ -135,14 +135,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
             // residual rows of all five passes are requested BEFORE the first store: hipcc cannot move a load of R above an
             // earlier store to Y (the two may alias for all it knows), so written pass by pass every residual load sat out a
             // full HBM latency behind the previous pass's store — 20 serial round trips per wave, most of a K = 320 tile's time
+            // (one hoisted operand: the residual where there is one — conv2, out-projections, FF2 — else the per-branch row bias of
+            //  conv1; hoisting both, or the plain bias as well, costs registers the 256-row tile does not have: measured -25 %)
             h8 rres[5];
-            if (p.R) {
+            const bool hoist_rb = !p.R && p.rowbias;
+            if (p.R || hoist_rb) {
 #pragma unroll
                 for (int it = 0; it < 5; ++it) {
                     const int id = it * 64 + lane;
                     const int row = id / 20, c = (id - row * 20) * 8;
                     const int m = mrow0 + row < p.M ? mrow0 + row : p.M - 1;
-                    rres[it] = *reinterpret_cast<const h8*>(p.R + (long)m * p.ldr + nb + c);
+                    const half_t* src = p.R ? p.R + (long)m * p.ldr : p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N);
+                    rres[it] = *reinterpret_cast<const h8*>(src + nb + c);
                 }
             }
 #pragma unroll
@@ -160,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
                 }
                 if (p.rowbias) {
-                    const h8 bv = *reinterpret_cast<const h8*>(p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) + n);
+                    const h8 bv = hoist_rb ? rres[it] : *reinterpret_cast<const h8*>(p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) + n);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
                 }
