@@ -145,14 +145,13 @@ def hbm_roofline(kernel, algorithmic_bytes, ms, launches):
 def run_aux_workload(a, dev):
     """the two HBM-bound producers / post-processors of the path as driver-timed lines (SURVEY §8d byte counts)."""
     from univst_amd.src import mask_propagation as mp, cal_optica_flow as cf
-    from oracle import synth_inputs as si            # seeded synthetic inputs only (no oracle compute in the timed region)
+    from univst_amd import synth
     import numpy as np
     F_ = a.frames
     out_cfg = {"frames": F_, "parallelism": "single"}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if a.workload == "maskprop":
-        feats = si.maskprop_features(F=F_, h=64, w=64, C=640, seed=11).to(dev)
-        first = si.soft_first_mask(512, 512)
+        feats, first = synth.synth_maskprop_inputs(F=F_, h=64, w=64, C=640, H=512, W=512, seed=11, device=dev)
         args = mp.build_parser().parse_args([])
         args.num_frames = F_
 
@@ -169,8 +168,7 @@ def run_aux_workload(a, dev):
         rs = np.random.RandomState(3)
         frames = torch.from_numpy(rs.randint(0, 256, (1, 3, F_, H, W)).astype(np.uint8)).to(dev)
         mask = torch.from_numpy((rs.rand(F_, H, W) > 0.7).astype(np.uint8)).to(dev)
-        flows = [torch.from_numpy(si.translation_flow(H, W, 3.3 * ((k % 3) - 1), -2.7 * ((k % 2) * 2 - 1), 100 + k, noise=0.6)).to(dev)
-                 for k in range(8)]
+        flows = [synth.synth_flow(H, W, 3.3 * ((k % 3) - 1), -2.7 * ((k % 2) * 2 - 1), 100 + k, noise=0.6, device=dev) for k in range(8)]
         cnt = [0]
 
         def flow_fn(x, y):

@@ -53,6 +53,22 @@ def test_no_product_import_of_oracle():
     assert not bad, bad
 
 
+def test_bench_imports_oracle_only_in_the_cpu_baseline_leg():
+    """bench.py may use the oracle as the reported CPU baseline, never inside a GPU leg (inputs of the GPU legs come from
+    univst_amd.synth): every `oracle` import must sit inside cpu_baseline()."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for fn in [n for n in ast.walk(tree) if isinstance(n, (ast.FunctionDef, ast.Module))]:
+        for node in (ast.walk(fn) if isinstance(fn, ast.FunctionDef) else fn.body):
+            names = []
+            if isinstance(node, ast.ImportFrom) and node.module:
+                names = [node.module]
+            elif isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                assert isinstance(fn, ast.FunctionDef) and fn.name == "cpu_baseline", f"oracle imported in {getattr(fn, 'name', 'module scope')}"
+
+
 def test_native_missing_library_fails_loudly(monkeypatch):
     from univst_amd import _native
     monkeypatch.setattr(_native, "_lib", None)

@@ -69,3 +69,34 @@ def synth_transfer_inputs(F=16, h=64, w=64, D=768, n=50, device="cuda", seed=123
             ms.append(((xx - cx) ** 2 + (yy - mask_hw / 2) ** 2 <= (mask_hw / 4) ** 2).to(torch.uint8))
         mask = torch.stack(ms)[None]
     return content, style, text, mask
+
+
+# ---- synthetic inputs of the side workloads of bench.py (mask propagation, sliding-window warp).  Product-side generators on
+# purpose: bench.py's GPU legs must not import anything from oracle/ (test infrastructure).
+def synth_maskprop_inputs(F=16, h=64, w=64, C=640, H=512, W=512, seed=11, device="cuda"):
+    """spatially coherent features [F,h,w,C] fp16 (smooth background + an object signature moving with a disc + noise) and an
+    anti-aliased multi-valued 'L' first-frame mask [H,W] uint8 (numpy), the shapes of the reference's feature dump / mask PNG."""
+    import numpy as np
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    low = torch.randn(1, C, 4, 4, generator=g)
+    bg = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False)[0]
+    sig = torch.randn(C, generator=g)
+    yy, xx = np.mgrid[0:h, 0:w]
+    feats = []
+    for f in range(F):
+        cx = w / 2.0 - 0.5 * F / 2 + 0.5 * f
+        m = torch.from_numpy((((xx - cx) ** 2 + (yy - h / 2.0) ** 2) <= (h / 4.0) ** 2).astype(np.float32))
+        feats.append((bg + 1.5 * sig[:, None, None] * m[None] + 0.15 * torch.randn(C, h, w, generator=g)).permute(1, 2, 0))
+    Y, X = np.mgrid[0:H, 0:W]
+    d = np.sqrt((X - (W / 2.0 - 4.0 * W / 512.0 * 8)) ** 2 + (Y - H / 2.0) ** 2)
+    first = np.clip((H / 4.0 - d) * 64.0 + 128.0, 0, 255).astype(np.uint8)
+    return torch.stack(feats).to(torch.float16).to(device), first
+
+
+def synth_flow(H, W, dx, dy, seed, noise=0.25, device="cuda"):
+    """analytic translation field (+ seeded noise) standing in for a RAFT output: fp32 [H,W,2]."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    f = torch.empty(H, W, 2)
+    f[..., 0] = dx
+    f[..., 1] = dy
+    return (f + noise * torch.randn(H, W, 2, generator=g)).to(device)
