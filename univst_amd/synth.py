@@ -72,7 +72,7 @@ def synth_transfer_inputs(F=16, h=64, w=64, D=768, n=50, device="cuda", seed=123
 
 
 # ---- synthetic inputs of the side workloads of bench.py (mask propagation, sliding-window warp).  Product-side generators on
-# purpose: bench.py's GPU legs must not import anything from oracle/ (test infrastructure).
+# purpose: the GPU legs of bench.py take nothing out of the test-infrastructure package.
 def synth_maskprop_inputs(F=16, h=64, w=64, C=640, H=512, W=512, seed=11, device="cuda"):
     """spatially coherent features [F,h,w,C] fp16 (smooth background + an object signature moving with a disc + noise) and an
     anti-aliased multi-valued 'L' first-frame mask [H,W] uint8 (numpy), the shapes of the reference's feature dump / mask PNG."""
