@@ -342,7 +342,7 @@ def main():
                 classes[k] = dict(ms_per_step=round(v["ms"] / nprof, 3), launches_per_step=round(v["launches"] / nprof, 1),
                                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
                                   gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
-        mfma = [k for k in prof if k.startswith(("gemm", "attn")) and prof[k]["launches"]]
+        mfma = [k for k in prof if k.startswith(("gemm", "attn", "conv")) and prof[k]["launches"]]
         dom = max(mfma, key=lambda k: prof[k]["ms"])
         d = prof[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
