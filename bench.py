@@ -358,7 +358,8 @@ def main():
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("round") and f.endswith("_pmc_traffic.json"))
             pm = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["kernels"]
             key = dom.replace(" ", "")
-            hit = [v for k, v in pm.items() if key.split("<")[0] in k and key.split("<")[1].rstrip(">") in k.replace(" ", "")]
+            base, targ = key.split("<")[0], (key.split("<")[1].rstrip(">") if "<" in key else "")
+            hit = [v for k, v in pm.items() if base in k and targ in k.replace(" ", "")]
             if hit and world == 1:      # a class may span several symbols (the 256- and 192-row tile): launch-weighted mean
                 nl = sum(v["launches_sampled"] for v in hit)
                 out["roofline"]["traffic"] = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] for v in hit) / max(nl, 1))

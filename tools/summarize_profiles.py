@@ -44,7 +44,7 @@ json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE 
 try:
     b = json.loads(open(os.path.join(O, f"round{RND}_bench_under_rocprof.json")).read().strip().splitlines()[-1])
     dom = b["roofline"]["kernel"]
-    base, targ = dom.split("<")[0], dom.split("<")[1].rstrip(">").replace(" ", "")
+    base, targ = dom.split("<")[0], (dom.split("<")[1].rstrip(">").replace(" ", "") if "<" in dom else "")
     rows = [r for r in csv.DictReader(open(ks)) if base in r["Name"] and targ in r["Name"].replace(" ", "")]
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
     open(os.path.join(O, f"round{RND}_agreement.txt"), "w").write(
