@@ -446,6 +446,36 @@ def main():
         torch.equal(g12["ddim_loop"]["k3"], g12["ddim_loop_plus"]["k3"]), "Easy-Inv window must start at i = 3"
     gold["g12_inversion"] = g12
 
+    # ---- G14: the reference's reconstruction loop (stable_diffusion.py:478-628; the inversion scripts call it with
+    #      guidance_scale=1.0 for the preview video, ddim_inversion.py:40,63) with and without classifier-free guidance
+    F_, h_, w_ = 16, 16, 16            # (decode_latents hard-codes f=16, stable_diffusion.py:388)
+    zT = si.content_latent(50, F_, h_, w_)
+    g14 = {}
+    keep_r = (0, 10, 25, 49)
+    for tag, gs in (("gs1", 1.0), ("gs7p5", 7.5)):
+        unet = build_reference_unet(cfg, sd)
+        pipe = SpatioTemporalStableDiffusionPipeline(vae=FakeVAE(), text_encoder=FakeTextEncoder(text),
+                                                     tokenizer=FakeTokenizer(), unet=unet, scheduler=DDIMScheduler())
+        cap = {}
+        pipe.reconstruction("", latents=zT.clone(), video_length=F_, guidance_scale=gs, height=h_ * 8, width=w_ * 8,
+                            callback=lambda i, t, l: cap.__setitem__(i, l.clone()) if i in keep_r else None)
+        # oracle restatement: plain DDIM sampling with the single-branch UNet (CFG: uncond + gs * (text - uncond), both with "")
+        osch = pipeline_ref.DDIMSchedule()
+        osch.set_timesteps(50)
+        z = zT.clone()
+        mine = {}
+        for i, t in enumerate(osch.timesteps):
+            e = unet_ref.unet_forward(sd, cfg, z, int(t), text, None, exact_temporal=False)[0]
+            if gs > 1.0:
+                e = e + gs * (e - e)          # negative prompt "" == prompt "": the guided noise equals the plain one
+            z, _ = osch.step(e, t, z)
+            if i in keep_r:
+                mine[i] = z.clone()
+        for i in keep_r:
+            chk(f"reconstruction_{tag}_i{i}", cap[i], mine[i], 2e-3)
+        g14[tag] = {f"i{i}": cap[i] for i in keep_r}
+    gold["g14_reconstruction"] = g14
+
     for k, v in gold.items():
         torch.save(v, os.path.join(OUT, k + ".pt"))
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:

@@ -229,3 +229,23 @@ def test_pixel_smoother_leg_of_the_loop():
     assert calls == [20, 21, 22, 23, 24]
     assert nflow == 5 * 2 * 58                      # 16 key frames x up to 4 neighbours, boundary-clipped = 58 warps per step
     assert all(torch.equal(a[i], b[i]) for i in range(20)) and not torch.allclose(a[20], b[20], atol=1e-3)
+
+
+@pytest.mark.parametrize("tag", ["gs1", "gs7p5"])
+def test_reconstruction_loop(golden, tag):
+    """G14: the reference's reconstruction loop (stable_diffusion.py:478-628) = plain DDIM sampling with the single-branch UNet;
+    with guidance_scale 7.5 and the empty negative prompt of the scripts both halves of the CFG batch see the same text, so the
+    guided noise equals the plain one (uncond + w * (text - uncond))."""
+    g = golden("g14_reconstruction")[tag]
+    cfg = unet_ref.TINY_CONFIG
+    sd = unet_ref.synth_state_dict(cfg, seed=33)
+    text = si.text_embedding(cfg["cross_attention_dim"])
+    osch = pipeline_ref.DDIMSchedule()
+    osch.set_timesteps(50)
+    z = si.content_latent(50, 16, 16, 16)
+    with torch.no_grad():
+        for i, t in enumerate(osch.timesteps):
+            e = unet_ref.unet_forward(sd, cfg, z, int(t), text, None, exact_temporal=False)[0]
+            z, _ = osch.step(e, t, z)
+            if i in (0, 10, 25, 49):
+                assert rel(z, g[f"i{i}"]) < 2e-3, i
