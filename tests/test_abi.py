@@ -84,3 +84,27 @@ def test_unet_forward_refuses_cpu():
                                       norm_num_groups=8)
     with pytest.raises(RuntimeError, match="no CPU path"):
         unet(torch.zeros(1, 4, 2, 16, 16), 1, torch.zeros(1, 77, 32))
+
+
+def test_pipeline_input_checks_match_the_reference():
+    """stable_diffusion.py:413-476: check_inputs / prepare_latents raise the reference's ValueErrors (no GPU needed)."""
+    import types
+    import torch
+    from univst_amd.backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
+    from univst_amd.schedulers import DDIMScheduler
+    pipe = SpatioTemporalStableDiffusionPipeline(vae=None, text_encoder=None, tokenizer=None, unet=types.SimpleNamespace(), scheduler=DDIMScheduler())
+    with pytest.raises(ValueError, match="`prompt` has to be of type `str` or `list`"):
+        pipe.check_inputs(3, 512, 512, 1)
+    with pytest.raises(ValueError, match="divisible by 8 but are 500 and 512"):
+        pipe.check_inputs("", 500, 512, 1)
+    with pytest.raises(ValueError, match="`callback_steps` has to be a positive integer"):
+        pipe.check_inputs("", 512, 512, 0)
+    pipe.check_inputs(["a", "b"], 512, 256, 2)
+    dev = torch.device("cpu")
+    z = pipe.prepare_latents(1, 4, 16, 512, 512, torch.float32, dev, torch.Generator().manual_seed(0))
+    assert tuple(z.shape) == (1, 4, 16, 64, 64)
+    with pytest.raises(ValueError, match="Unexpected latents shape"):
+        pipe.prepare_latents(1, 4, 16, 512, 512, torch.float32, dev, None, latents=torch.zeros(1, 4, 8, 64, 64))
+    with pytest.raises(ValueError, match="list of generators of length 2"):
+        pipe.prepare_latents(1, 4, 16, 512, 512, torch.float32, dev, [torch.Generator(), torch.Generator()])
+    assert pipe.prepare_extra_step_kwargs(None, 0.0) == {"eta": 0.0, "generator": None}      # DDIMScheduler.step takes both (:402-410)

@@ -249,3 +249,16 @@ def test_reconstruction_loop(golden, tag):
             z, _ = osch.step(e, t, z)
             if i in (0, 10, 25, 49):
                 assert rel(z, g[f"i{i}"]) < 2e-3, i
+
+
+def test_product_scheduler_step_matches_g7(golden):
+    """univst_amd.schedulers.DDIMScheduler.step (the API-completeness method; the loops use the folded axpby kernel) and its
+    timestep table against G7 (restated diffusers 0.35.1 DDIM, eta = 0) over all 50 timesteps."""
+    from univst_amd.schedulers import DDIMScheduler
+    g = golden("g7_ddim")
+    s = DDIMScheduler()
+    s.set_timesteps(50)
+    assert torch.equal(s.timesteps, g["timesteps"])
+    for i, t in enumerate(g["timesteps"]):
+        out = s.step(g["e"], int(t), g["z"])
+        assert torch.equal(out.prev_sample, g["prev"][i]), int(t)

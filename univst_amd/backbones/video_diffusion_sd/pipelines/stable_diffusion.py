@@ -47,6 +47,61 @@ class SpatioTemporalStableDiffusionPipeline:
     def _execution_device(self):
         return self.device
 
+    # ------------------------------------------------------------------ plumbing kept from the reference (:142-176, 396-476)
+    def enable_vae_slicing(self):
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    def enable_sequential_cpu_offload(self, gpu_id=0):
+        """the reference offloads unet / text_encoder / vae through accelerate; the native UNet keeps its weights in a device
+        arena and cannot be paged, so only the two third-party modules are offloaded."""
+        try:
+            from accelerate import cpu_offload
+        except ImportError:
+            raise ImportError("Please install accelerate via `pip install accelerate`")
+        device = torch.device(f"cuda:{gpu_id}")
+        for m in (self.text_encoder, self.vae):
+            if m is not None:
+                cpu_offload(m, device)
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        keys = set(inspect.signature(self.scheduler.step).parameters.keys())
+        kw = {}
+        if "eta" in keys:
+            kw["eta"] = eta
+        if "generator" in keys:
+            kw["generator"] = generator
+        return kw
+
+    def check_inputs(self, prompt, height, width, callback_steps):
+        """stable_diffusion.py:413-428: same conditions, same messages."""
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (callback_steps is not None and (not isinstance(callback_steps, int) or callback_steps <= 0)):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+
+    def prepare_latents(self, batch_size, num_channels_latents, clip_length, height, width, dtype, device, generator, latents=None):
+        """stable_diffusion.py:430-476."""
+        shape = (batch_size, num_channels_latents, clip_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            if isinstance(generator, list):
+                one = (1,) + shape[1:]
+                latents = torch.cat([torch.randn(one, generator=generator[i], device=device, dtype=dtype) for i in range(batch_size)], dim=0)
+            else:
+                latents = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
+            latents = latents.to(device)
+        return latents * getattr(self.scheduler, "init_noise_sigma", 1.0)
+
     # ------------------------------------------------------------------ prompt (stable_diffusion.py:193-308)
     def _encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt):
         batch_size = len(prompt) if isinstance(prompt, list) else 1
@@ -118,13 +173,14 @@ class SpatioTemporalStableDiffusionPipeline:
                        output_type="tensor", return_dict=True, callback=None, callback_steps=1, **kwargs):
         if eta != 0.0:
             raise NotImplementedError("eta != 0")
+        self.check_inputs(prompt, height, width, callback_steps)
+        batch_size = 1 if isinstance(prompt, str) else len(prompt)
         device = self._execution_device
         cfg = guidance_scale > 1.0
         text = self._encode_prompt(prompt, device, num_images_per_prompt, cfg, negative_prompt)
         self.scheduler.set_timesteps(num_inference_steps)
-        if latents is None:
-            shape = (1, self.unet.config.in_channels, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
-            latents = torch.randn(shape, generator=generator, device=device, dtype=text.dtype)
+        latents = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.config.in_channels, video_length, height, width,
+                                       text.dtype, device, generator, latents)
         latents = latents.to(device=device, dtype=torch.float16).contiguous()
         for i, t in enumerate(self.scheduler.timesteps):
             x = torch.cat([latents] * 2) if cfg else latents

@@ -53,3 +53,19 @@ class DDIMScheduler:
         ratio = self.config.num_train_timesteps // num_inference_steps
         ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
         self.timesteps = torch.from_numpy(ts)
+
+    def step(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict: bool = True):
+        """DDIMScheduler.step, eta = 0 (API completeness for callers that drive the scheduler themselves; the pipelines and
+        engine.ddim_step fold the same update into one axpby kernel launch).  Tensor arithmetic on the inputs' device."""
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0")
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        x0 = (sample - (1 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        prev = a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * model_output
+        if not return_dict:
+            return (prev,)
+        return _Cfg(prev_sample=prev, pred_original_sample=x0)
