@@ -31,11 +31,39 @@ def warp_accumulate_(acc, key, now, fwd, bwd, threshold=1.5):
     return acc
 
 
-def get_warp(flow_fn, image1, image2):
-    """uint8 [H,W,3] device tensors -> warped/occlusion-composited uint8 [H,W,3]."""
-    acc = torch.zeros(*image1.shape, dtype=torch.float32, device=image1.device)
-    warp_accumulate_(acc, image1.contiguous(), image2.contiguous(), flow_fn(image1, image2), flow_fn(image2, image1))
-    return acc.to(torch.uint8)
+_RAFT = {}
+
+
+def get_warp(image1_path, image2_path, ref_image1=None, ref_image2=None, occlusion_mask_save_path=None, warped_image_save_path=None,
+             flow_fn=None):
+    """cal_optica_flow.py:51-99, same positional arguments: flows between image1 and image2 (forward = image1 -> image2), occlusion
+    test at 1.5 px, ``ref_image2`` warped by the forward flow and composited over ``ref_image1`` where occluded, uint8 [H,W,3].
+    Images may be numpy arrays (the reference's calling convention: a numpy array comes back), uint8 device tensors (a device tensor
+    comes back) or file paths.  ``flow_fn`` stands in for RAFT (third-party); when omitted the torchvision model is created ONCE per
+    process (the reference re-creates it on every call, :53-55).  The ``*_save_path`` debugging outputs need cv2 and are not supported."""
+    if occlusion_mask_save_path is not None or warped_image_save_path is not None:
+        raise NotImplementedError("occlusion_mask_save_path / warped_image_save_path need cv2.imwrite")
+    import numpy as np
+
+    def dev(img):
+        if isinstance(img, str):
+            from PIL import Image
+            img = np.array(Image.open(img).convert("RGB"))
+        if isinstance(img, np.ndarray):
+            return torch.from_numpy(np.ascontiguousarray(img)).cuda(), True
+        return img.contiguous(), False
+    a, was_np = dev(image1_path)
+    b, _ = dev(image2_path)
+    ra = a if ref_image1 is None else dev(ref_image1)[0]
+    rb = b if ref_image2 is None else dev(ref_image2)[0]
+    if flow_fn is None:
+        if "fn" not in _RAFT:
+            _RAFT["fn"] = make_raft_flow_fn(a.device)
+        flow_fn = _RAFT["fn"]
+    acc = torch.zeros(*a.shape, dtype=torch.float32, device=a.device)
+    warp_accumulate_(acc, ra, rb, flow_fn(a, b), flow_fn(b, a))
+    out = acc.to(torch.uint8)
+    return out.cpu().numpy() if was_np else out
 
 
 @torch.no_grad()

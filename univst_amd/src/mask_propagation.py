@@ -26,6 +26,26 @@ def to_one_hot(y_tensor, n_dims=None):
     return oh.view(h, w, n_dims).permute(2, 0, 1).unsqueeze(0).cuda()
 
 
+def read_feature(path, frame_index, return_h_w=False):
+    """mask_propagation.py:102-111: one frame of the dumped feature file as [h*w, C] fp32 on the GPU.  (Kept for callers of the
+    reference's helper; ``propagate_masks`` reads the file ONCE instead of once per frame and queue slot.)"""
+    data = torch.load(path, weights_only=True).to("cuda").float()[frame_index]
+    _h, _w, _ = data.shape
+    data = data.view(_h * _w, -1).contiguous()
+    return (data, _h, _w) if return_h_w else data
+
+
+def norm_mask(mask):
+    """mask_propagation.py:114-123: per-class min-max to [0,1] for classes whose max is > 0, in place.  (Kept for callers of the
+    reference's helper; the pipeline's own path fuses upsample + this + the arg-max in csrc/maskprop.hip.)"""
+    mx = mask.flatten(1).max(dim=1).values
+    mn = mask.flatten(1).min(dim=1).values
+    sel = mx > 0
+    rng = (mx - mn)[sel][:, None, None]
+    mask[sel] = (mask[sel] - mn[sel][:, None, None]) / rng
+    return mask
+
+
 def _ws(nbytes, device):
     return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
 
