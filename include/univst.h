@@ -84,11 +84,26 @@ typedef int (*univst_kv_exchange_fn)(void* user, int64_t off_send_last, int64_t 
 int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int64_t comm_ws_bytes,
                          univst_allreduce_fn ar, univst_kv_exchange_fn kv, void* user);
 
+/* tuning switches of a handle (not part of the reference's surface; tests use them for A/B runs).
+ *   "ln_fold" (default 1, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
+ *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU). */
+int univst_unet_set_option(univst_unet* h, const char* name, int value);
+
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
 /* Y[M,N] = X[M,K] W[N,K]^T + bias + residual; geglu: W rows must be pre-interleaved, writes N/2 columns.
  * Replaces torch Linear / 1x1 conv call sites attention.py:123,141,375-377,425. */
 int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr,
                   void* Y, int64_t ldy, int M, int N, int K, int geglu, void* stream);
+/* The same linear with a LayerNorm folded into it and / or row statistics emitted for the next one (what the UNet graph does with
+ * norm1/2/3 of a transformer block, attention.py:311-329).  Only for problems the direct 256x320 tile takes (N % 320 == 0, at
+ * least 150 tiles; else UNIVST_ERR_ARG).
+ *   stats_out (may be NULL): fp32 [M][N/160][2] <- (sum, sum of squares) of the stored fp16 outputs per 160-column slot.
+ *   ln_stats  (may be NULL): fp32 [M][K/160][2] written by the linear that produced X.  Then X holds the RAW rows, W must be
+ *             fp16(gamma[k] * W[n][k]), ln_wsum[n] = sum_k of that, ln_bias[n] = bias[n] + sum_k beta[k] W[n][k] (fp32), bias NULL,
+ *             and Y = rstd * (X W^T - mean * ln_wsum) + ln_bias  ==  LayerNorm(X) W_orig^T + bias  (+ residual, GEGLU as usual). */
+int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr,
+                     void* Y, int64_t ldy, int M, int N, int K, int geglu, const float* ln_stats, float ln_eps,
+                     const float* ln_wsum, const float* ln_bias, float* stats_out, void* stream);
 /* NHWC implicit-GEMM conv: taps 9 (3x3, pad 1) or 1; optional second source (channel concat), fused nearest x2
  * upsample of the input, stride 1/2.  W is [Cout][taps][C1+C2].  Replaces resnet.py:57-80,145,226. */
 int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, int stride,

@@ -454,3 +454,55 @@ def test_mask_resize(nat):
     ref = F.interpolate(m[None].float(), size=(64, 64), mode="bilinear", align_corners=False)[0]
     got = nat.mask_resize(m, 64, 64)
     assert torch.equal(got.float(), ref), "mask resize values {0,.25,.5,.75,1} must be exact"
+
+
+@pytest.mark.parametrize("M,C,Nf,geglu,res", [(49152, 320, 960, False, False), (49152, 320, 320, False, True), (49152, 640, 5120, True, False),
+                                              (40000, 1280, 1280, False, False)])
+def test_linear_layernorm_fold(nat, M, C, Nf, geglu, res):
+    """univst_linear_ln: a producer linear leaves (sum, sumsq) per row and 160-column slot; the consumer runs on the raw rows with
+    gamma folded into the weight and applies rstd * (acc - mean * wsum) + lnb.  Reference: torch fp32 LayerNorm -> linear
+    (-> GEGLU / + residual) on the producer's fp16 output.  fp16 tolerance: 2e-3 of the output scale (max), 5e-4 rms."""
+    g = torch.Generator().manual_seed(M + C + Nf)
+    x0 = torch.randn(M, C, generator=g).half().cuda()
+    wp = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    bp = (0.7 + 0.3 * torch.randn(C, generator=g)).half().cuda()          # rows with a mean well away from 0
+    stats = torch.full((M, C // 160, 2), float("nan"), device="cuda", dtype=torch.float32)
+    x = nat.linear_ln(x0, wp, bias=bp, stats_out=stats)
+    assert torch.equal(x, nat.linear(x0, wp, bias=bp)), "emitting the statistics must not change the output"
+    xf = x.float()
+    want_st = torch.stack([xf.view(M, C // 160, 160).sum(-1), (xf * xf).view(M, C // 160, 160).sum(-1)], -1)
+    assert torch.allclose(stats, want_st, rtol=2e-5, atol=1e-3), (stats - want_st).abs().max().item()
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).half().cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).half().cuda()
+    w = (torch.randn(Nf, C, generator=g) / math.sqrt(C)).half().cuda()
+    b = (0.1 * torch.randn(Nf, generator=g)).half().cuda()
+    r = torch.randn(M, Nf, generator=g).half().cuda() if res else None
+    wref, bref = w, b
+    if geglu:          # rows interleaved [16 x | 16 gate] as the kernel expects
+        idx = []
+        for q in range(Nf // 32):
+            idx += list(range(16 * q, 16 * q + 16)) + list(range(Nf // 2 + 16 * q, Nf // 2 + 16 * q + 16))
+        idx = torch.tensor(idx).cuda()
+        w, b = w[idx].contiguous(), b[idx].contiguous()
+    wl = (w.float() * gamma.float()[None]).half()
+    wsum = wl.float().sum(1).contiguous()
+    lnb = (b.float() + w.float() @ beta.float()).contiguous()
+    got = nat.linear_ln(x, wl, residual=r, geglu=geglu, ln=(stats, wsum, lnb)).float()
+    xn = torch.nn.functional.layer_norm(xf, (C,), gamma.float(), beta.float(), 1e-5)
+    y = xn @ wref.float().t() + bref.float()
+    if geglu:
+        a, gate = y.chunk(2, dim=-1)
+        y = a * F.gelu(gate)
+    if res:
+        y = y + r.float()
+    scale = y.abs().max().item()
+    mx = (got - y).abs().max().item() / scale
+    rms = ((got - y).pow(2).mean().sqrt() / y.pow(2).mean().sqrt()).item()
+    assert mx < 2e-3 and rms < 5e-4, (mx, rms)
+
+
+def test_linear_layernorm_fold_rejects_small_problems(nat):
+    x = torch.randn(1024, 320).half().cuda()
+    w = torch.randn(320, 320).half().cuda()
+    with pytest.raises(RuntimeError, match="not taken by the direct"):
+        nat.linear_ln(x, w, stats_out=torch.empty(1024, 2, 2, device="cuda"))

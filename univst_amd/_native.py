@@ -40,7 +40,9 @@ SIGNATURES = {
     "univst_unet_reserve": (_I, [_P, _I, _I, _I, _I]),
     "univst_unet_forward": (_I, [_P, _P, _F, _P, _I, _I, _I, _I, _I, C.POINTER(PnP), _P, _P, _I, _P]),
     "univst_unet_set_comm": (_I, [_P, _I, _I, _P, _L, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
+    "univst_unet_set_option": (_I, [_P, C.c_char_p, _I]),
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
+    "univst_linear_ln": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv3x3_patch": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
@@ -120,6 +122,23 @@ def linear(x, w, bias=None, residual=None, geglu=False, out=None):
         out = torch.empty(M, No, device=x.device, dtype=torch.float16)
     check(load().univst_linear(ptr(x), K, ptr(w), ptr(bias), ptr(residual), No, ptr(out), No, M, N, K, int(geglu),
                                stream_ptr()), "linear")
+    return out
+
+
+def linear_ln(x, w, bias=None, residual=None, geglu=False, out=None, ln=None, stats_out=None, eps=1e-5):
+    """``linear`` through the LayerNorm-fold entry: ``stats_out`` fp32 [M, N/160, 2] receives the row statistics of the output;
+    ``ln = (stats [M, K/160, 2], wsum [N], lnb [N])`` folds LayerNorm(x) into this linear (w = gamma-scaled weight)."""
+    _f16(x), _f16(w)
+    M, K = x.shape
+    N = w.shape[0]
+    No = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(M, No, device=x.device, dtype=torch.float16)
+    st, ws, lb = ln if ln is not None else (None, None, None)
+    for t in (st, ws, lb, stats_out):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    check(load().univst_linear_ln(ptr(x), K, ptr(w), ptr(bias), ptr(residual), No, ptr(out), No, M, N, K, int(geglu), ptr(st), eps,
+                                  ptr(ws), ptr(lb), ptr(stats_out), stream_ptr()), "linear_ln")
     return out
 
 

@@ -373,6 +373,8 @@ class UNetPseudo3DConditionModel(nn.Module):
                           f"load_tensor({name})")
         torch.cuda.current_stream().synchronize()   # sources may be temporaries
         _native.check(lib.univst_unet_finalize(h, stream), "unet_finalize")
+        for k, v in getattr(self, "_native_options", {}).items():
+            _native.check(lib.univst_unet_set_option(h, k.encode(), int(v)), f"unet_set_option({k})")
         self._native_handle = h
         self._native_dirty = False
         self._native_fp = fp
@@ -385,6 +387,14 @@ class UNetPseudo3DConditionModel(nn.Module):
         for t in self.state_dict(keep_vars=True).values():
             acc = (acc * 1000003 + t.data_ptr() + 7919 * t._version) & 0xFFFFFFFFFFFFFFFF
         return acc
+
+    def set_native_option(self, name: str, value: int):
+        """tuning switch of the native graph (include/univst.h ``univst_unet_set_option``), e.g. ``("ln_fold", 0)``; survives rebuilds."""
+        if not hasattr(self, "_native_options"):
+            self._native_options = {}
+        self._native_options[name] = int(value)
+        if getattr(self, "_native_handle", None) is not None:
+            _native.check(_native.load().univst_unet_set_option(self._native_handle, name.encode(), int(value)), f"unet_set_option({name})")
 
     def invalidate_native(self):
         """force a rebuild of the native weight copy at the next forward."""

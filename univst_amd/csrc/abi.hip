@@ -1,5 +1,7 @@
 // extern "C" surface of libunivst_hip.so (include/univst.h).  Thin argument checking + dispatch.
 #include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <new>
 
@@ -43,8 +45,19 @@ int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     univst_unet* h = new (std::nothrow) univst_unet();
     UV_REQUIRE(h, "unet_create: out of host memory");
     h->impl.cfg = *cfg;
+    if (const char* e = getenv("UNIVST_LN_FOLD")) h->impl.ln_fold = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     *out = h;
     return UV_OK;
+}
+int univst_unet_set_option(univst_unet* h, const char* name, int value) {
+    UV_REQUIRE(h && name, "unet_set_option: null argument");
+    if (!strcmp(name, "ln_fold")) {
+        UV_REQUIRE(value >= 0 && value <= 2, "unet_set_option: ln_fold is 0, 1 or 2");
+        h->impl.ln_fold = value;
+        return UV_OK;
+    }
+    uv_set_error("unet_set_option: unknown option '%s'", name);
+    return UV_ERR_ARG;
 }
 int univst_unet_destroy(univst_unet* h) {
     delete h;
@@ -87,6 +100,18 @@ int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, c
     GemmParams g;
     g.X = H(X); g.ldx = ldx; g.W = H(W); g.bias = H(bias); g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy;
     g.M = M; g.N = N; g.K = K; g.geglu = geglu;
+    return uv_launch_gemm(g, 0, S(s));
+}
+int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                     int M, int N, int K, int geglu, const float* ln_stats, float ln_eps, const float* ln_wsum, const float* ln_bias,
+                     float* stats_out, void* s) {
+    UV_REQUIRE(X && W && Y, "linear_ln: null argument");
+    UV_REQUIRE(!ln_stats || (ln_wsum && ln_bias && K % 160 == 0 && !bias), "linear_ln: a folded LayerNorm needs wsum, lnb (which holds the bias) and K %% 160 == 0");
+    UV_REQUIRE(uv_linear_takes_big_direct(M, N, K), "linear_ln: M=%d N=%d K=%d is not taken by the direct 256x320 path (N %% 320 == 0 and >= 150 tiles)", M, N, K);
+    GemmParams g;
+    g.X = H(X); g.ldx = ldx; g.W = H(W); g.bias = H(bias); g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy;
+    g.M = M; g.N = N; g.K = K; g.geglu = geglu;
+    g.ln_stats = ln_stats; g.ln_slots = K / 160; g.ln_eps = ln_eps; g.ln_wsum = ln_wsum; g.ln_bias = ln_bias; g.stats_out = stats_out;
     return uv_launch_gemm(g, 0, S(s));
 }
 int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int up, int stride, int taps,

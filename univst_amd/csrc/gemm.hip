@@ -29,12 +29,56 @@ namespace {
 // source of every out-of-range / padding 16-byte piece of the GLDS path (LDS-DMA cannot write immediates)
 __device__ __attribute__((aligned(256))) half_t uv_zero_page[128];
 
+// ---- epilogue constants of a tile's 320 output columns, in LDS (gemm_big_kernel / conv_patch_kernel).
+// A load placed between two stores of the epilogue waits (vmcnt is one in-order counter on gfx9) for the earlier store's write
+// acknowledgement: with the bias fetched inside the store loop every 16-byte store of a K = 320 tile cost a full round trip to L2.
+// The per-column constants are therefore fetched ONCE, while the first operand tile is in flight, into a small LDS array next to
+// the operand buffers; the store loops read them with ds_read and the only global loads left are the residual rows, requested
+// up front.  Layout (floats): [0,320) ln_wsum | [320,640) ln_bias | halfs: bias[320] bias2[320] | float2 (mean, rstd) of 256 rows.
+constexpr int EPC_LNB = 320, EPC_HALFS = 640, EPC_ROWST = 960, EPC_TOTAL = 960 + 512;
+template <int LNF>
+__device__ __forceinline__ void epi_const_stage(const GemmParams& p, int m0, int n0, int bmb, int tid, float* epc) {
+    half_t* hb = reinterpret_cast<half_t*>(epc + EPC_HALFS);
+    if (tid < 320) {
+        const int n = n0 + tid;
+        const bool ok = n < p.N;
+        hb[tid] = (p.bias && ok) ? p.bias[n] : (half_t)0.f;
+        hb[320 + tid] = (p.bias2 && ok) ? p.bias2[n] : (half_t)0.f;
+        if (LNF == 2) {
+            epc[tid] = ok ? p.ln_wsum[n] : 0.f;
+            epc[EPC_LNB + tid] = ok ? p.ln_bias[n] : 0.f;
+        }
+    }
+    if (LNF == 2 && tid < bmb) {     // (mean, rstd) of the tile's rows from the producer's per-slot (sum, sumsq): LayerNorm over K
+        float s1 = 0.f, s2 = 0.f;
+        if (m0 + tid < p.M) {
+            const float2* sp = reinterpret_cast<const float2*>(p.ln_stats) + (long)(m0 + tid) * p.ln_slots;
+            for (int e = 0; e < p.ln_slots; ++e) {
+                const float2 t = sp[e];
+                s1 += t.x;
+                s2 += t.y;
+            }
+        }
+        const float inv = 1.f / (float)p.K;
+        const float mean = s1 * inv;
+        const float var = fmaxf(fmaf(-mean, mean, s2 * inv), 0.f);
+        reinterpret_cast<float2*>(epc + EPC_ROWST)[tid] = float2{mean, rsqrtf(var + p.ln_eps)};
+    }
+}
+
 // Epilogue for ONE output row m: col[i][r] is output channel nb + i*16 + g*4 + r.  bias / per-branch row bias /
 // residual / second bias (added after fp16 rounding) / GEGLU on interleaved [16 x | 16 gate] channel blocks.
-template <int NF>
-__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 (&col)[NF], int m, int nb, int g) {
+// cf: the block's LDS constants (null: the 128-row kernels read bias / bias2 from memory), cn = nb - n0.
+// LNF (256 x 320 linear kernel only): the LayerNorm that precedes this linear is folded into the epilogue.  With W' = gamma (.) W
+// (fp16, made at finalize), wsum[n] = sum_k W'[n][k] and lnb[n] = bias[n] + sum_k beta[k] W[n][k]:
+//     LN(x) W^T + bias  =  rstd * (x W'^T  -  mean * wsum)  +  lnb
+// so the GEMM runs on the RAW rows x and (mean, rstd) of a row — `ln` — enter only here.
+template <int NF, int LNF = 0, bool CL = false>       // CL: per-column constants from LDS (cf), else from memory
+__device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 (&col)[NF], int m, int nb, int g, const float* cf = nullptr,
+                                                  int cn = 0, float2 ln = float2{0.f, 1.f}) {
     if (m >= p.M) return;
     const half_t* rbias = p.rowbias ? p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) : nullptr;
+    const half_t* hb = CL ? reinterpret_cast<const half_t*>(cf + EPC_HALFS) + cn : nullptr;
     if (p.geglu) {
         if constexpr (NF % 2 == 0) {
 #pragma unroll
@@ -44,9 +88,27 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                 if (ng >= p.N) continue;
                 const int no = nb / 2 + (i / 2) * 16 + g * 4;
                 h4 o, bx = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-                if (p.bias) {                               // (hoisting these 64-byte L1 hits out of the store loop measured -3 %)
-                    bx = *reinterpret_cast<const h4*>(p.bias + nx);
-                    bg = *reinterpret_cast<const h4*>(p.bias + ng);
+                if (LNF == 2) {
+                    const float* cc = cf + cn + i * 16 + g * 4;
+                    const f4 wx = *reinterpret_cast<const f4*>(cc), wg = *reinterpret_cast<const f4*>(cc + 16);
+                    const f4 cx = *reinterpret_cast<const f4*>(cc + EPC_LNB), cg = *reinterpret_cast<const f4*>(cc + EPC_LNB + 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float xv = fmaf(ln.y, fmaf(-ln.x, wx[r], col[i][r]), cx[r]);
+                        const float gv = fmaf(ln.y, fmaf(-ln.x, wg[r], col[i + 1][r]), cg[r]);
+                        o[r] = (half_t)(xv * gelu_erf_f(gv));
+                    }
+                    *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + no) = o;
+                    continue;
+                }
+                if (p.bias) {
+                    if constexpr (CL) {
+                        bx = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4);
+                        bg = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4 + 16);
+                    } else {
+                        bx = *reinterpret_cast<const h4*>(p.bias + nx);
+                        bg = *reinterpret_cast<const h4*>(p.bias + ng);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -75,8 +137,15 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = col[i][r];
         if (n + 3 < p.N) {
+            if (LNF == 2) {
+                const f4 ws = *reinterpret_cast<const f4*>(cf + cn + i * 16 + g * 4), cb = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + i * 16 + g * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(ln.y, fmaf(-ln.x, ws[r], v[r]), cb[r]);
+            }
             if (p.bias) {
-                h4 bv = *reinterpret_cast<const h4*>(p.bias + n);
+                h4 bv;
+                if constexpr (CL) bv = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4);
+                else bv = *reinterpret_cast<const h4*>(p.bias + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
             }
@@ -92,7 +161,9 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
             }
             h4 o;
             if (p.bias2) {
-                h4 bv = *reinterpret_cast<const h4*>(p.bias2 + n);
+                h4 bv;
+                if constexpr (CL) bv = *reinterpret_cast<const h4*>(hb + 320 + i * 16 + g * 4);
+                else bv = *reinterpret_cast<const h4*>(p.bias2 + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)((float)(half_t)v[r] + (float)bv[r]);
             } else {
@@ -121,9 +192,15 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
 // ds_write_b128) and reads it back row-major, so residual loads and output stores are 16 B per lane over 320 contiguous bytes.
 // Arithmetic order is that of gemm_epilogue_row (fp32: acc + bias + rowbias + residual, one rounding, then bias2).
 constexpr int EPI_LDW = 164;
-template <int MJ>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 (&acc)[10][MJ], float* slab, int mw, int nb, int lane) {
+// LDS map of the row-statistics producer (bytes; the operand buffers are dead by then): the eight transpose slabs end at
+// 8 * 16 * 164 * 4 = 83968; per-wave scratch from 90112 (8 x 2560 B).  The 192-row tile has 128 KB of LDS, the 256-row one 144 KB.
+constexpr int EPI_STAT_SCRATCH = 90112;
+// cf: the block's LDS constants, cn = nb - n0, rw = first tile row of this wave; scratch: this wave's statistics scratch (LNF).
+template <int MJ, int LNF = 0>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 (&acc)[10][MJ], float* slab, int mw, int nb, int lane,
+                                                  const float* cf, int cn, int rw = 0, float2* scratch = nullptr) {
     const int l15 = lane & 15, g = lane >> 4;
+    const half_t* hb = reinterpret_cast<const half_t*>(cf + EPC_HALFS) + cn;
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
 #pragma unroll
@@ -132,11 +209,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
         __builtin_amdgcn_wave_barrier();
         const int mrow0 = mw + j * 16;
         if (!p.geglu) {
-            // residual rows of all five passes are requested BEFORE the first store: hipcc cannot move a load of R above an
-            // earlier store to Y (the two may alias for all it knows), so written pass by pass every residual load sat out a
-            // full HBM latency behind the previous pass's store — 20 serial round trips per wave, most of a K = 320 tile's time
-            // (one hoisted operand: the residual where there is one — conv2, out-projections, FF2 — else the per-branch row bias of
-            //  conv1; hoisting both, or the plain bias as well, costs registers the 256-row tile does not have: measured -25 %)
+            // residual rows of all five passes are requested BEFORE the first store (one hoisted operand: the residual where there
+            // is one — conv2, out-projections, FF2 — else the per-branch row bias of conv1; the per-column constants come from LDS)
             h8 rres[5];
             const bool hoist_rb = !p.R && p.rowbias;
             if (p.R || hoist_rb) {
@@ -151,15 +225,27 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
             }
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
-                const int id = it * 64 + lane;
+                // (opaque to the optimiser on purpose: with the loops unrolled hipcc otherwise computes the 64-bit row pointers of all
+                //  20 passes up front, spills them, and the scratch reloads queue behind the stores like any other load)
+                int id = it * 64 + lane;
+                asm volatile("" : "+v"(id) : : "memory");
                 const int row = id / 20, c = (id - row * 20) * 8;
                 const int m = mrow0 + row, n = nb + c;
                 const f4 v0 = *reinterpret_cast<const f4*>(&slab[row * EPI_LDW + c]);
                 const f4 v1 = *reinterpret_cast<const f4*>(&slab[row * EPI_LDW + c + 4]);
                 if (m >= p.M) continue;
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (LNF == 2) {
+                    const float2 ln = reinterpret_cast<const float2*>(cf + EPC_ROWST)[rw + j * 16 + row];
+                    const f4 w0 = *reinterpret_cast<const f4*>(cf + cn + c), w1 = *reinterpret_cast<const f4*>(cf + cn + c + 4);
+                    const f4 c0 = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + c), c1 = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + c + 4);
+                    const float ws[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    const float cb[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = fmaf(ln.y, fmaf(-ln.x, ws[r], v[r]), cb[r]);
+                }
                 if (p.bias) {
-                    const h8 bv = *reinterpret_cast<const h8*>(p.bias + n);
+                    const h8 bv = *reinterpret_cast<const h8*>(hb + c);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
                 }
@@ -175,7 +261,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                 }
                 h8 o;
                 if (p.bias2) {
-                    const h8 bv = *reinterpret_cast<const h8*>(p.bias2 + n);
+                    const h8 bv = *reinterpret_cast<const h8*>(hb + 320 + c);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) o[r] = (half_t)((float)(half_t)v[r] + (float)bv[r]);
                 } else {
@@ -183,6 +269,36 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
                 }
                 *reinterpret_cast<h8*>(p.Y + (long)m * p.ldy + n) = o;
+                if (LNF == 1) {           // (sum, sum of squares) of the 8 values AS STORED: what the consuming GEMM will read
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float t = (float)o[r];
+                        s1 += t;
+                        s2 = fmaf(t, t, s2);
+                    }
+                    scratch[id] = float2{s1, s2};
+                }
+            }
+            if (LNF == 1) {
+                // 16 rows x 20 partials -> one (sum, sumsq) per row and 160-column slot, summed in a fixed order (lane = row*4 + q adds
+                // partials 5q..5q+4, then the four q) so the statistics are reproducible
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int row = lane >> 2, q = lane & 3;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 5; ++e) {
+                    const float2 t = scratch[row * 20 + q * 5 + e];
+                    s1 += t.x;
+                    s2 += t.y;
+                }
+                s1 += __shfl_xor(s1, 1, 64);
+                s2 += __shfl_xor(s2, 1, 64);
+                s1 += __shfl_xor(s1, 2, 64);
+                s2 += __shfl_xor(s2, 2, 64);
+                const int m = mrow0 + row;
+                if (q == 0 && m < p.M) *reinterpret_cast<float2*>(p.stats_out + ((long)m * (p.N / 160) + nb / 160) * 2) = float2{s1, s2};
             }
         } else {
             // interleaved [16 x | 16 gate] channel blocks -> 80 output columns per row: 16 rows x 10 chunks of 8
@@ -200,8 +316,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                 float xv[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
                 float gv[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                 if (p.bias) {
-                    const h8 bx = *reinterpret_cast<const h8*>(p.bias + nb + cx);
-                    const h8 bg = *reinterpret_cast<const h8*>(p.bias + nb + cx + 16);
+                    const h8 bx = *reinterpret_cast<const h8*>(hb + cx);
+                    const h8 bg = *reinterpret_cast<const h8*>(hb + cx + 16);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) { xv[r] += (float)bx[r]; gv[r] += (float)bg[r]; }
                 }
@@ -215,6 +331,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
         __builtin_amdgcn_wave_barrier();
     }
 }
+
 
 constexpr int BM_DEFAULT = 128;
 
@@ -413,13 +530,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 // operand traffic per flop is 2.2x lower than the 128x128 kernel, which is what lifts the L2-bandwidth ceiling
 // those tiles sit on.  Staging is global_load_lds only (two 72 KB LDS buffers, unpadded 128 B
 // rows, XOR-swizzled chunks), one barrier per 64-wide k tile, 80 MFMAs per wave between barriers.
-template <int MODE, int MJ>
+// LNF: 0 plain, 1 emits the row statistics of its output (GemmParams::stats_out), 2 folds a LayerNorm of its input (ln_stats)
+template <int MODE, int MJ, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     // MJ = 16-row fragments per wave along M: 4 -> 256-row tile, 3 -> 192-row tile (same kernel, chosen per problem so that
     // the tile count fills whole rounds of the 256 CUs: 49152 and 12288 rows are 256 / 64 tiles of 192)
     constexpr int NF = 10, BMB = 64 * MJ, BNB = 320, BK = 64, LDSH = 64;
     constexpr int TILE = (BMB + BNB) * LDSH;                 // halfs per buffer (72 KB)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
+    __shared__ __attribute__((aligned(16))) float epc[EPC_TOTAL];      // epilogue constants (epi_const_stage)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -552,14 +671,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         }
     };
 
+    const int nk = kt1 - kt0;
+    issue_tile(kt0 * BK, 0);
+    if (p.splits <= 1) epi_const_stage<LNF>(p, m0, n0, BMB, tid, epc);      // lands with the first tile, visible after the first barrier
     f4 acc[NF][MJ];
 #pragma unroll
     for (int i = 0; i < NF; ++i)
 #pragma unroll
         for (int j = 0; j < MJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = kt1 - kt0;
-    issue_tile(kt0 * BK, 0);
     const int sw = l15 & 7;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                  // vmcnt(0) + barrier: tile kt landed everywhere, buffer (kt+1)&1 is free
@@ -595,7 +714,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
     if (p.epi_lds) {
         __syncthreads();                  // every wave is done with the operand tiles: smem becomes the transpose scratch
-        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane);
+        gemm_epilogue_lds<MJ, LNF>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160,
+                                   wm * 16 * MJ, reinterpret_cast<float2*>(reinterpret_cast<char*>(smem) + EPI_STAT_SCRATCH) + wave * 320);
         return;
     }
 #pragma unroll
@@ -603,7 +723,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         f4 col[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
-        gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MJ + j * 16 + l15, n0 + wn * 160, g);
+        gemm_epilogue_row<NF, LNF, true>(p, col, m0 + wm * 16 * MJ + j * 16 + l15, n0 + wn * 160, g, epc, wn * 160,
+                                   (LNF == 2) ? reinterpret_cast<const float2*>(epc + EPC_ROWST)[wm * 16 * MJ + j * 16 + l15] : float2{0.f, 1.f});
     }
 }
 
@@ -634,6 +755,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     constexpr int PBUF = PROUNDS * 512 * 8;                  // halfs per patch buffer (32 KB)
     constexpr int WT = BNB * LDSH;                           // halfs per weight buffer (40 KB)
     __shared__ __attribute__((aligned(16))) half_t smem[2 * PBUF + 2 * WT];     // 144 KB
+    __shared__ __attribute__((aligned(16))) float epc[EPC_TOTAL];                // epilogue constants (epi_const_stage)
     half_t* const Pb = smem;
     half_t* const Wb = smem + 2 * PBUF;
 
@@ -714,12 +836,6 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         pbase[j] = (ry + seps) * PW + rx;
     }
 
-    f4 acc[NF][MJ];
-#pragma unroll
-    for (int i = 0; i < NF; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-
     const int nslab_all = (p.C1 + p.C2) / 32;
     const int s_begin = p.splits > 1 ? split * (p.ktps / 9) * 2 : 0;
     const int s_end = p.splits > 1 ? (s_begin + (p.ktps / 9) * 2 < nslab_all ? s_begin + (p.ktps / 9) * 2 : nslab_all) : nslab_all;
@@ -729,6 +845,12 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     issue_patch(s_begin);
     if (nslab > 1) issue_patch(s_begin + 1);
     issue_w(t_off);
+    if (p.splits <= 1) epi_const_stage<0>(p, m0, n0, BMB, tid, epc);
+    f4 acc[NF][MJ];
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     int next_patch = 2;                                      // next slab to stage, relative to s_begin
     int u_slab = s_begin, u_tap = 0;
     const int sw = l15 & 7;
@@ -772,7 +894,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     }
     if (p.epi_lds) {
         __syncthreads();
-        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane);
+        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160);
         return;
     }
 #pragma unroll
@@ -780,7 +902,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         f4 col[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
-        gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MJ + j * 16 + l15, n0 + wn * 160, g);
+        gemm_epilogue_row<NF, 0, true>(p, col, m0 + wm * 16 * MJ + j * 16 + l15, n0 + wn * 160, g, epc, wn * 160);
     }
 }
 
@@ -852,8 +974,20 @@ static bool uv_conv_patch_eligible(const GemmParams& p, int bmb) {
            bmb % p.Wo == 0 && (bmb / p.Wo + 2 + bmb / p.Wo / p.Ho + 1) * (p.Wo + 2) <= 512 && !p.geglu;
 }
 
+// Does a plain linear of this shape take the direct (no split-K) 256x320 path whose epilogue can fold a LayerNorm / emit row
+// statistics?  Mirrors the dispatch in uv_launch_gemm (which re-checks and fails loudly on a mismatch).
+bool uv_linear_takes_big_direct(long M, int N, int K) {
+    static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
+    static const long bigmin_env = getenv("UNIVST_GEMM_BIGMIN") ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 0;
+    const long bigmin = bigmin_env ? bigmin_env : 150;
+    if (nobig || N % 320 != 0 || (long)N * K >= (1L << 31) || M * (long)K >= (1L << 31)) return false;
+    const long n256 = ((M + 255) / 256) * (N / 320), n192 = ((M + 191) / 192) * (N / 320);
+    return n256 >= bigmin && n192 >= bigmin;      // whichever tile height the launcher picks
+}
+
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    const bool lnf = p.ln_stats || p.stats_out;
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
     if (mode == 0) {
         UV_REQUIRE(p.ldx % 8 == 0, "gemm: ldx=%ld must be a multiple of 8", p.ldx);
@@ -937,7 +1071,19 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                 UV_LAUNCH_CHECK();
                 return UV_OK;
             }
-            if (use192) {
+            if (lnf) {                // LayerNorm folded into this linear / row statistics emitted for the next one
+                if (p.geglu) q.epi_lds = 0;
+                UV_REQUIRE(mode == 0 && q.splits == 1 && (q.epi_lds || !p.stats_out) && (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0)) &&
+                           (!p.stats_out || (!p.geglu && p.N % 160 == 0)), "linear: LayerNorm fold on a problem the direct 256x320 path does not take");
+                UV_REQUIRE(!(p.ln_stats && p.stats_out), "linear: a LayerNorm-folded linear cannot also emit row statistics");
+                if (p.ln_stats) {
+                    if (use192) hipLaunchKernelGGL((gemm_big_kernel<0, 3, 2>), bgrid, dim3(512), 0, stream, q);
+                    else hipLaunchKernelGGL((gemm_big_kernel<0, 4, 2>), bgrid, dim3(512), 0, stream, q);
+                } else {
+                    if (use192) hipLaunchKernelGGL((gemm_big_kernel<0, 3, 1>), bgrid, dim3(512), 0, stream, q);
+                    else hipLaunchKernelGGL((gemm_big_kernel<0, 4, 1>), bgrid, dim3(512), 0, stream, q);
+                }
+            } else if (use192) {
                 if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0, 3>), bgrid, dim3(512), 0, stream, q);
                 else hipLaunchKernelGGL((gemm_big_kernel<1, 3>), bgrid, dim3(512), 0, stream, q);
             } else if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0, 4>), bgrid, dim3(512), 0, stream, q);
@@ -951,6 +1097,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             return UV_OK;
         }
     }
+    UV_REQUIRE(!lnf, "linear: LayerNorm fold requested for M=%d N=%d K=%d, which the 256x320 path does not take (uv_linear_takes_big_direct)", p.M, p.N, p.K);
     bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0) ;
     int BN = nf5 ? 160 : 128;
     int nt = ((p.M + BM_DEFAULT - 1) / BM_DEFAULT) * ((p.N + BN - 1) / BN);

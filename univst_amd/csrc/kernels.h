@@ -33,6 +33,16 @@ struct GemmParams {
     size_t partial_bytes = 0;
     int splits = 1, ktps = 0;          // set by the launcher
     int issue_mode = 0;                // 256x320 kernel, A/B aid: how the next tile's DMA is spread over the current tile's MFMAs
+    // LayerNorm folded into the linears around it (256x320 direct path only, uv_linear_takes_big_direct):
+    //  producer: stats_out[m][N/160][2] <- (sum, sum of squares) of the stored fp16 outputs per 160-column slot;
+    //  consumer: X holds the RAW rows, W = gamma (.) W, and the epilogue computes rstd*(acc - mean*ln_wsum[n]) + ln_bias[n]
+    //            with (mean, rstd) over K from ln_stats[m][ln_slots][2]  (ln_bias already contains the linear's own bias).
+    float* stats_out = nullptr;
+    const float* ln_stats = nullptr;
+    int ln_slots = 0;
+    float ln_eps = 0.f;
+    const float* ln_wsum = nullptr;    // [N] fp32: sum_k W'[n][k]
+    const float* ln_bias = nullptr;    // [N] fp32: bias[n] + sum_k beta[k] W[n][k]
 };
 
 struct AttnParams {
@@ -51,6 +61,7 @@ struct AttnParams {
 };
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
+bool uv_linear_takes_big_direct(long M, int N, int K);
 constexpr size_t UV_SPLITK_WS_BYTES = 128u << 20;  // fp32 partials [splits][M][N]: 8 splits of the 8x8-level convs (3072 x 1280)
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);

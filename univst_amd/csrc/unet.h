@@ -41,6 +41,7 @@ struct UNet {
     long temb_total = 0;
     Arena arena;
     bool finalized = false;
+    int ln_fold = 1;          // transformer-block LayerNorms folded into the neighbouring linears: 0 none, 1 norm1 + norm2, 2 also norm3 (UNIVST_LN_FOLD)
     unsigned* d_counter = nullptr;
     std::string missing;
     // multi-GPU frame sharding hooks

@@ -75,6 +75,31 @@ __global__ void scale_f16_kernel(const half_t* __restrict__ in, half_t* __restri
     if (i < n) out[i] = (half_t)((float)in[i] * f);
 }
 
+// LayerNorm folded into the following linear (GemmParams::ln_stats): W'[n][k] = fp16(gamma[k] * W[n][k]), wsum[n] = sum_k W'[n][k]
+// (of the ROUNDED values: it has to cancel mean * sum_k W' exactly), lnb[n] = bias[n] + sum_k beta[k] * W[n][k].  One wave per row.
+__global__ __launch_bounds__(64) void ln_fold_weight_kernel(const half_t* __restrict__ W, const half_t* __restrict__ gamma,
+                                                            const half_t* __restrict__ beta, const half_t* __restrict__ bias,
+                                                            half_t* __restrict__ Wout, float* __restrict__ wsum, float* __restrict__ lnb, int K) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f, b = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = (float)W[(long)n * K + k];
+        const half_t wp = (half_t)(w * (float)gamma[k]);
+        Wout[(long)n * K + k] = wp;
+        s += (float)wp;
+        b = fmaf((float)beta[k], w, b);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    if (lane == 0) {
+        wsum[n] = s;
+        lnb[n] = b + (bias ? (float)bias[n] : 0.f);
+    }
+}
+
 __global__ void count_not_dirac_kernel(const half_t* __restrict__ w, int Co, int Ci, int k, unsigned* cnt) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)Co * Ci * k) return;
@@ -300,6 +325,29 @@ int UNet::finalize(hipStream_t s) {
             hipLaunchKernelGGL(geglu_interleave_kernel, dim3(nb((long)rows * cols)), dim3(256), 0, s, t.ptr, d, rows, cols);
         }
     }
+    // LayerNorm-folded copies of the three linears that follow norm1 / norm2 / norm3 of every transformer block
+    for (const std::string& k : keys) {
+        if (!ends(k, ".transformer_blocks.0.norm1.weight")) continue;
+        const std::string b = k.substr(0, k.size() - strlen(".norm1.weight"));
+        struct { const char* norm; std::string w; std::string bias; } jobs[3] = {
+            {".norm1", b + (find(b + ".attn1.qkv#fused#qs") ? ".attn1.qkv#fused#qs" : ".attn1.qkv#fused"), ""},
+            {".norm2", b + (find(b + ".attn2.to_q.weight#qs") ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight"), ""},
+            {".norm3", b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu"}};
+        for (auto& j : jobs) {
+            const WTensor *w = find(j.w), *gm = find(b + j.norm + ".weight"), *bt = find(b + j.norm + ".bias");
+            const WTensor* bi = j.bias.empty() ? nullptr : find(j.bias);
+            UV_REQUIRE(w && gm && bt && (j.bias.empty() || bi) && w->shape.size() == 2 && gm->shape[0] == w->shape[1],
+                       "%s: LayerNorm / linear pair incomplete", (b + j.norm).c_str());
+            const long N = w->shape[0], K = w->shape[1];
+            half_t *wo, *ws, *lb;
+            int rc = derive_alloc(j.w + "#ln", {N, K}, &wo);
+            if (!rc) rc = derive_alloc(j.w + "#ln.wsum", {2 * N}, &ws);      // fp32 [N]
+            if (!rc) rc = derive_alloc(j.w + "#ln.bias", {2 * N}, &lb);      // fp32 [N]
+            if (rc) return rc;
+            hipLaunchKernelGGL(ln_fold_weight_kernel, dim3((unsigned)N), dim3(64), 0, s, w->ptr, gm->ptr, bt->ptr, bi ? bi->ptr : nullptr, wo,
+                               (float*)ws, (float*)lb, (int)K);
+        }
+    }
     {   // all resnets' time_emb_proj stacked into one [sum Cout, 4*C0] matrix: one projection launch per forward instead of 22
         std::vector<std::string> tk;
         for (const std::string& k : keys)
@@ -486,23 +534,35 @@ struct Fwd {
         g.partial_bytes = UV_SPLITK_WS_BYTES;
         return uv_launch_gemm(g, 1, s);
     }
+    // stats_out: emit the per-row (sum, sumsq) of Y for a following folded LayerNorm.  ln_in: fold LayerNorm(X) (statistics in ln_in,
+    // ln_slots = K / 160 slots per row) into this linear: `wkey` then names the derived "#ln" weight and the bias comes with it.
     int linear(const half_t* X, long ldx, long M, int K, const std::string& wkey, const std::string& bkey, int N, half_t* Y,
-               long ldy, const half_t* R = nullptr, long ldr = 0, const half_t* bias2 = nullptr, int geglu = 0) {
+               long ldy, const half_t* R = nullptr, long ldr = 0, const half_t* bias2 = nullptr, int geglu = 0, float* stats_out = nullptr,
+               const float* ln_in = nullptr) {
         GemmParams g;
+        g.stats_out = stats_out;
+        if (ln_in) {
+            g.ln_stats = ln_in;
+            g.ln_slots = K / 160;
+            g.ln_eps = 1e-5f;
+            g.ln_wsum = (const float*)W(wkey + ".wsum");
+            g.ln_bias = (const float*)W(wkey + ".bias");
+            if (!g.ln_wsum || !g.ln_bias) return u.missing_error();
+        }
         g.X = X;
         g.ldx = ldx;
         g.M = (int)M;
         g.K = K;
         g.N = N;
         g.W = W(wkey);
-        g.bias = bkey.empty() ? nullptr : W(bkey);
+        g.bias = (bkey.empty() || ln_in) ? nullptr : W(bkey);
         g.Y = Y;
         g.ldy = ldy;
         g.R = R;
         g.ldr = ldr;
         g.bias2 = bias2;
         g.geglu = geglu;
-        if (!g.W || (!bkey.empty() && !g.bias)) return u.missing_error();
+        if (!g.W || (!bkey.empty() && !ln_in && !g.bias)) return u.missing_error();
         g.partial = sk_ws;
         g.partial_bytes = UV_SPLITK_WS_BYTES;
         return uv_launch_gemm(g, 0, s);
@@ -571,17 +631,29 @@ struct Fwd {
         RUN(groupnorm(x, nullptr, N, 1e-6f, p + ".norm", 0, t0));
         half_t* h = alloc(rows * C);
         if (!h) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight"), p + ".proj_in.bias", C, h, C));
+        // The three LayerNorms of the block are folded into the linears around them when all of those take the direct 256x320 path
+        // (levels with >= 150 tiles: the 64x64 .. 16x16 levels of an unsharded clip): the producing linear's epilogue leaves the row
+        // statistics, the consuming one runs on the raw rows — no LayerNorm launch, no normalised copy in HBM.
+        // norm3 -> GEGLU projection is folded only on request (ln_fold = 2): its epilogue is the longest of the block and the fold
+        // costs it more than the LayerNorm launch it removes (tools/bench_ln_fold.py).
+        const bool fold = u.ln_fold > 0 && C % 160 == 0 && uv_linear_takes_big_direct(rows, C, C) && uv_linear_takes_big_direct(rows, 3 * C, C);
+        const bool fold3 = fold && u.ln_fold > 1 && uv_linear_takes_big_direct(rows, 8 * C, C);
+        float* lnst = fold ? (float*)alloc(rows * (C / 160) * 4) : nullptr;      // [rows][C/160][2] fp32
+        if (fold && !lnst) return UV_ERR_STATE;
+        RUN(linear(t0, C, rows, C, p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight"), p + ".proj_in.bias", C, h, C,
+                   nullptr, 0, nullptr, 0, lnst));
         // ---- attn1
         half_t *gm, *bt;
         gm = W(b + ".norm1.weight"); bt = W(b + ".norm1.bias");
         if (!gm || !bt) return u.missing_error();
-        RUN(uv_launch_layernorm(h, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+        if (!fold) RUN(uv_launch_layernorm(h, C, t0, C, gm, bt, rows, C, 1e-5f, s));
         const long extra_rows = u.world > 1 ? (long)2 * B * N : 0;     // received prev-frame + first-frame K/V (frame shard)
         half_t* qkv = alloc((rows + extra_rows) * 3 * C);
         if (!qkv) return UV_ERR_STATE;
         const bool qs = u.find(b + ".attn1.qkv#fused#qs") != nullptr;      // head_dim 40: scale folded into to_q (finalize)
-        RUN(linear(t0, C, rows, C, b + (qs ? ".attn1.qkv#fused#qs" : ".attn1.qkv#fused"), "", 3 * C, qkv, 3 * C));
+        const std::string wqkv = b + (qs ? ".attn1.qkv#fused#qs" : ".attn1.qkv#fused");
+        if (fold) RUN(linear(h, C, rows, C, wqkv + "#ln", "", 3 * C, qkv, 3 * C, nullptr, 0, nullptr, 0, nullptr, lnst));
+        else RUN(linear(t0, C, rows, C, wqkv, "", 3 * C, qkv, 3 * C));
         const bool registered = pnp_layer && pnp && pnp->registered;
         if (registered && pnp->idx >= pnp->eta1 && pnp->idx <= pnp->eta2 * 50.f) {
             UV_REQUIRE(B == 3, "PnP attention shift needs the three-branch batch (B=3), got B=%d", B);
@@ -604,17 +676,19 @@ struct Fwd {
         free(qkv);
         half_t* h2 = alloc(rows * C);
         if (!h2) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2, C, h, C));
+        RUN(linear(t0, C, rows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2, C, h, C, nullptr, 0, lnst));
         free(h);
         // ---- attn2 (text)
         gm = W(b + ".norm2.weight"); bt = W(b + ".norm2.bias");
         if (!gm || !bt) return u.missing_error();
-        RUN(uv_launch_layernorm(h2, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+        if (!fold) RUN(uv_launch_layernorm(h2, C, t0, C, gm, bt, rows, C, 1e-5f, s));
         half_t* q2 = alloc(rows * C);
         half_t* kv = alloc((long)B * text_len * 2 * C);
         if (!q2 || !kv) return UV_ERR_STATE;
         const bool qs2 = u.find(b + ".attn2.to_q.weight#qs") != nullptr;
-        RUN(linear(t0, C, rows, C, b + (qs2 ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight"), "", C, q2, C));
+        const std::string wq2 = b + (qs2 ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight");
+        if (fold) RUN(linear(h2, C, rows, C, wq2 + "#ln", "", C, q2, C, nullptr, 0, nullptr, 0, nullptr, lnst));
+        else RUN(linear(t0, C, rows, C, wq2, "", C, q2, C));
         RUN(linear(text, u.cfg.cross_attention_dim, (long)B * text_len, u.cfg.cross_attention_dim, b + ".attn2.kv#fused", "",
                    2 * C, kv, 2 * C));
         ap.q = q2; ap.ldq = C;
@@ -627,16 +701,21 @@ struct Fwd {
         free(kv);
         half_t* h3 = alloc(rows * C);
         if (!h3) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3, C, h2, C));
+        RUN(linear(t0, C, rows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3, C, h2, C, nullptr, 0, fold3 ? lnst : nullptr));
         free(h2);
         // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
         gm = W(b + ".norm3.weight"); bt = W(b + ".norm3.bias");
         if (!gm || !bt) return u.missing_error();
-        RUN(uv_launch_layernorm(h3, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+        if (!fold3) RUN(uv_launch_layernorm(h3, C, t0, C, gm, bt, rows, C, 1e-5f, s));
         half_t* mid = alloc(rows * 4 * C);
         if (!mid) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu", 8 * C, mid, 4 * C, nullptr,
-                   0, nullptr, 1));
+        if (lnst && !fold3) free(lnst);
+        if (fold3) {
+            RUN(linear(h3, C, rows, C, b + ".ff.net.0.proj.weight#geglu#ln", "", 8 * C, mid, 4 * C, nullptr, 0, nullptr, 1, nullptr, lnst));
+            free(lnst);
+        } else
+            RUN(linear(t0, C, rows, C, b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu", 8 * C, mid, 4 * C, nullptr,
+                       0, nullptr, 1));
         half_t* tb = W(b + ".attn_temporal.to_out.0.bias");
         if (!tb) return u.missing_error();
         half_t* h4 = alloc(rows * C);
