@@ -537,8 +537,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     // the tile count fills whole rounds of the 256 CUs: 49152 and 12288 rows are 256 / 64 tiles of 192)
     constexpr int NF = 10, BMB = 64 * MJ, BNB = 320, BK = 64, LDSH = 64;
     constexpr int TILE = (BMB + BNB) * LDSH;                 // halfs per buffer (72 KB)
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
-    __shared__ __attribute__((aligned(16))) float epc[EPC_TOTAL];      // epilogue constants (epi_const_stage)
+    // ONE LDS object on purpose: with a second __shared__ array hipcc keeps pointer provenance on every LDS access and then puts a
+    // vmcnt(0) in front of the fragment reads of each k tile ("may alias the LDS-DMA in flight"), which serialises DMA and MFMAs
+    // (-25 % on the long-K linears).  The epilogue constants (epi_const_stage) live behind the two operand buffers.
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE + 2 * EPC_TOTAL];
+    float* const epc = reinterpret_cast<float*>(smem + 2 * TILE);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -683,12 +686,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();                  // vmcnt(0) + barrier: tile kt landed everywhere, buffer (kt+1)&1 is free
         const bool more = kt + 1 < nk;
-        if (more) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1, p.issue_mode ? 1 : 3);
+        if (more) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1, 1);      // activation rows now, weight rows before the second k-half
         const half_t* Xs = smem + (kt & 1) * TILE;
         const half_t* Ws = Xs + BMB * LDSH;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (ks == 1 && more && p.issue_mode) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1, 2);
+            if (ks == 1 && more) issue_tile((kt0 + kt + 1) * BK, (kt + 1) & 1, 2);
             const int ch = ((ks * 4 + g) ^ sw) * 8;
             h8 a[NF];
 #pragma unroll
@@ -754,8 +757,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     constexpr int PROUNDS = 4;                               // DMA rounds per patch (512 lanes x 16 B each)
     constexpr int PBUF = PROUNDS * 512 * 8;                  // halfs per patch buffer (32 KB)
     constexpr int WT = BNB * LDSH;                           // halfs per weight buffer (40 KB)
-    __shared__ __attribute__((aligned(16))) half_t smem[2 * PBUF + 2 * WT];     // 144 KB
-    __shared__ __attribute__((aligned(16))) float epc[EPC_TOTAL];                // epilogue constants (epi_const_stage)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * PBUF + 2 * WT + 2 * EPC_TOTAL];     // 144 KB + the epilogue constants (one LDS object: see gemm_big_kernel)
+    float* const epc = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WT);
     half_t* const Pb = smem;
     half_t* const Wb = smem + 2 * PBUF;
 
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         const half_t* Ws = Wb + ((t_off + t) & 1) * WT;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            if (ks == p.issue_mode && t + 1 < T) issue_w(t_off + t + 1);     // A/B aid UNIVST_CONV_PATCH_WISSUE: 0 = before the first k-half, 1 = before the second
+            if (ks == 1 && t + 1 < T) issue_w(t_off + t + 1);                // next weight tile: before the second k-half (measured better than before the first)
             const half_t* Ps = Pb + (u_slab & 1) * PBUF;
             const int ky = u_tap / 3, kx = u_tap - 3 * ky;
             const int delta = ky * PW + kx;
