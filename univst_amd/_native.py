@@ -9,7 +9,8 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunivst_hip.so")
+# UNIVST_LIB: another build of the same library (A/B measurements of kernel variants inside one process tree; tools/README.md)
+_LIB_PATH = os.environ.get("UNIVST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libunivst_hip.so")
 _lib = None
 
 

@@ -225,10 +225,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
             }
 #pragma unroll
             for (int it = 0; it < 5; ++it) {
-                // (opaque to the optimiser on purpose: with the loops unrolled hipcc otherwise computes the 64-bit row pointers of all
-                //  20 passes up front, spills them, and the scratch reloads queue behind the stores like any other load)
-                int id = it * 64 + lane;
-                asm volatile("" : "+v"(id) : : "memory");
+                const int id = it * 64 + lane;
                 const int row = id / 20, c = (id - row * 20) * 8;
                 const int m = mrow0 + row, n = nb + c;
                 const f4 v0 = *reinterpret_cast<const f4*>(&slab[row * EPI_LDW + c]);
