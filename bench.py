@@ -357,9 +357,11 @@ def main():
         try:
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("round") and f.endswith("_pmc_traffic.json"))
             pm = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["kernels"]
-            key = dom.replace(" ", "")
-            base, targ = key.split("<")[0], (key.split("<")[1].rstrip(">") if "<" in key else "")
-            hit = [v for k, v in pm.items() if base in k and targ in k.replace(" ", "")]
+            import re
+            # class label -> the kernel symbols it times (template arguments as rocprofv3 prints them; tools/summarize_profiles.py uses the same map)
+            pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
+                   "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0>"}.get(dom, re.escape(dom.replace(" ", "")))
+            hit = [v for k, v in pm.items() if re.search(pat, k.replace(" ", ""))]
             if hit and world == 1:      # a class may span several symbols (the 256- and 192-row tile): launch-weighted mean
                 nl = sum(v["launches_sampled"] for v in hit)
                 out["roofline"]["traffic"] = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] for v in hit) / max(nl, 1))

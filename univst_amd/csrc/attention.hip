@@ -348,7 +348,9 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // 1/64 and split in a multiple of 8 plus a remainder so both parts are exact in fp16; softmax is shift invariant, so a
 // quantised reference is not an approximation.  On a (rare) reference change the pending scores are shifted by the same
 // delta and O^T is rescaled after the pending PV, the order T13 requires.
-template <bool FOLD>
+// TAG only names the symbol: 0 = self-attention, 1 = the 77-key text cross-attention of the same level (same code; separate rows
+// in rocprofv3 --stats, so a per-symbol average means one kind of launch)
+template <bool FOLD, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     constexpr int D = 40, DV16 = 3, QB = 4, NST = 3;
     constexpr int KSTR = lds_stride_bytes(64 * 2) / 2;       // 80 halfs
@@ -754,8 +756,10 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         static const int pp = getenv("UNIVST_ATTN_PP") ? atoi(getenv("UNIVST_ATTN_PP")) : 2;
         if (p.Nq >= 2048 && ((pp == 2 && p.q_prescaled) || pp == 1)) {
             const int nqb4 = (p.Nq + 255) / 256;
-            if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
-            else hipLaunchKernelGGL((attn_pp40_kernel<false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            const bool text = p.nsrc == 1 && p.Nkv <= 128;
+            if (pp == 2 && text) hipLaunchKernelGGL((attn_pp40_kernel<true, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL((attn_pp40_kernel<false, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
             return UV_OK;
         }
