@@ -7,7 +7,8 @@ Workload (BASELINE.json metric): SD-v1.5 geometry UNet (random-init synthetic we
 fp16), 16 frames x 512x512 (latents [1,4,16,64,64]), 50 DDIM steps of the three-branch transfer loop
 (content-inv | style-inv | stylised) with AdaIN-guided attention injection on steps 0..25 and the latent AdaIN
 on steps 41..45, all three branches computed on every step (reference-equivalent work, 46.8 TFLOP/step).
-One "step" = one DDIM step of that loop (steps i = 0..K-1 of the 50-step schedule, wrapping modulo 50);
+One "step" = one DDIM step of that loop (K = 50: the whole schedule; K < 50: K steps spread evenly over it, i = floor(50 j / K), so the
+mix of in-window / out-of-window steps is the loop's; K > 50 wraps modulo 50);
 value = F / (50 * mean step time) frames/s — with the default K = 50 that is exactly one full transfer.
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
@@ -293,11 +294,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # which steps of the 50-step schedule are timed: all of them for K = 50 (wrapping for K > 50); for K < 50 the K steps are spread
+    # evenly over the schedule (i_j = floor(50 j / K)) so that the share of steps inside the PnP window (26 of 50), the mask blend
+    # (0..45) and the latent AdaIN (41..45) is that of the full loop — steps 0..K-1 would all be the (more expensive) in-window kind
+    idx = [(j * 50) // a.steps if a.steps < 50 else j % 50 for j in range(a.steps)]
     for i in range(a.warmup):
-        lat = step(i, lat)
+        lat = step(i % 50, lat)
     sync()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in idx:
         lat = step(i, lat)
     sync()
     dt = time.perf_counter() - t0
@@ -318,6 +323,7 @@ def main():
                                  f"sd15_unet_single_branch_ddim_inversion_{F_total}x{h * 8}x{h * 8}_50ddim") if inv else
                                 f"{a.model}_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
+                   "schedule_steps": "all 50" if a.steps == 50 else (f"{a.steps} of 50, evenly spread" if a.steps < 50 else f"{a.steps} (wrapping modulo 50)"),
                    "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
                    "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else
                                "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16")},
@@ -330,7 +336,7 @@ def main():
     if not a.no_profile:
         nprof = min(a.steps, 50)
         l2 = lat
-        for i in range(nprof):
+        for i in idx[:nprof]:
             l2 = step(i, l2)
         sync()
     if rank == 0 and not a.no_profile:
