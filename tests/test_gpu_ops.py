@@ -371,6 +371,32 @@ def test_attention_cross_77(nat):
     close(got, ref, rtol=4e-3)
 
 
+@pytest.mark.parametrize("heads,d,N,Nkv,pre", [(8, 40, 4096, 77, 1), (8, 40, 1000, 77, 0), (8, 80, 1024, 77, 0), (4, 80, 300, 80, 1),
+                                               (8, 40, 257, 13, 0), (2, 80, 2048 + 31, 64, 0), (8, 40, 640, 65, 1)])
+def test_attention_text_register_kernel(nat, heads, d, N, Nkv, pre):
+    """attn_text_kernel (one source of <= 80 keys, head_dim 40 / 80, K / V held in registers): ragged query counts (tails inside a
+    32-row wave tile, a 1024-row block chunk and the 128-row iteration), key counts that end inside any of the five key fragments,
+    prescaled and plain q, strided q / kv rows as the UNet graph passes them.  fp16 tolerance 4e-3 of the output scale."""
+    BF, B = 6, 3
+    C = heads * d
+    qbuf = rnd(BF, N, C + 64, seed=1)                 # row stride wider than C
+    q = qbuf[..., :C]
+    kv = rnd(B, Nkv, 2 * C, seed=2)
+    kv[1] *= 3.0                                       # one branch with peaked scores
+    k, v = kv[..., :C], kv[..., C:]
+    src = torch.tensor([[i // 2] for i in range(BF)], dtype=torch.int32).cuda()
+    if pre:
+        qp, qref = prescaled(q, d)
+        qpb = torch.zeros_like(qbuf)
+        qpb[..., :C] = qp
+        got = nat.attention(qpb[..., :C], k, v, src, heads, ldq=C + 64, ldkv=2 * C, Nkv=Nkv, C_=C, q_prescaled=True)
+    else:
+        qref = q
+        got = nat.attention(q, k, v, src, heads, ldq=C + 64, ldkv=2 * C, Nkv=Nkv, C_=C)
+    ref = sdpa_ref(qref, k.float().repeat_interleave(2, 0), v.float().repeat_interleave(2, 0), heads)
+    close(got, ref, rtol=4e-3)
+
+
 def test_attention_softmax_spike(nat):
     """force large running-max jumps between key tiles (online-softmax rescale path)."""
     heads, d, N = 2, 32, 256

@@ -1,5 +1,5 @@
 import sys, os, math, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from univst_amd import _native
 def run(heads, d, N, BF, pre):
     C = heads * d

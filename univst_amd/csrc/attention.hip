@@ -742,6 +742,176 @@ __global__ void tr16_probe_kernel(float* out) {
     for (int j = 0; j < 4; ++j) out[lane * 4 + j] = (float)v[j];
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Text cross-attention (attn2: one source of <= 80 keys, head_dim 40 / 80 — 10 of the 16 launches of a UNet call, 0.9 ms of
+// the step in the generic kernels, which pad 77 keys to two 64-key tiles, ring them through LDS with a barrier per tile and
+// give every block a zero-fill prologue for 256 queries of work).  Here K and V of the (branch, head) are staged ONCE per block
+// and then live in REGISTERS as MFMA A operands (5 key fragments x KS k-steps of K, DV16 x (32 + 32 + 16 keys) of V^T through
+// ds_read_b64_tr_b16); a wave then streams 32 query rows per iteration with no further barrier or LDS traffic: Q fragments
+// straight from memory (the B operand of S^T = K Q^T), all 80 scores of a row in registers (exact row max, no online
+// rescaling), P^T packed in place as the B operand of O^T = V^T P^T (80 keys = three 32-key steps, the last half empty) and 8-byte
+// stores of O.  What is left is the read of Q and the write of O.
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_text_kernel(AttnParams p) {
+    constexpr int KS = (D + 31) / 32, DV16 = (D + 15) / 16, NKF = 5, NKEY = NKF * 16, NIT = 8;
+    constexpr int KSTR = KS * 32 + 16;                       // halfs: 160 B (d=40) / 224 B (d=80) rows, conflict-free ds_read_b128
+    constexpr int VSTR = DV16 * 16;                          // 96 B / 160 B rows, conflict-free ds_read_b64_tr_b16
+    constexpr int DCH = D / 8;
+    __shared__ __attribute__((aligned(16))) half_t smem[NKEY * KSTR + NKEY * VSTR];
+    half_t* const Ks = smem;
+    half_t* const Vs = smem + NKEY * KSTR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nchunk = (p.Nq + 128 * NIT - 1) / (128 * NIT);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int chunk = lid % nchunk;
+    const int h = (lid / nchunk) % p.heads;
+    const int bf = lid / (nchunk * p.heads);
+    const float c = p.q_prescaled ? 1.f : p.scale_log2e;
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- K / V of this (source block, head) -> LDS (zero padded to 80 keys and to the fragment widths), once
+    for (int i = tid * 8; i < NKEY * KSTR + NKEY * VSTR; i += 256 * 8) *reinterpret_cast<h8*>(&smem[i]) = zero8;
+    __syncthreads();
+    {
+        const long kvrow0 = (long)p.src_idx[bf * p.nsrc] * p.Nkv;
+        for (int idx = tid; idx < p.Nkv * DCH; idx += 256) {
+            const int row = idx / DCH, ch = idx - row * DCH;
+            const long off = (kvrow0 + row) * p.ldkv + h * D + ch * 8;
+            *reinterpret_cast<h8*>(&Ks[row * KSTR + ch * 8]) = *reinterpret_cast<const h8*>(p.k + off);
+            *reinterpret_cast<h8*>(&Vs[row * VSTR + ch * 8]) = *reinterpret_cast<const h8*>(p.v + off);
+        }
+    }
+    __syncthreads();
+    h8 kf[NKF][KS];
+#pragma unroll
+    for (int kfi = 0; kfi < NKF; ++kfi)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[kfi][ks] = *reinterpret_cast<const h8*>(&Ks[(kfi * 16 + l15) * KSTR + ks * 32 + g * 8]);
+    // V^T fragments: lane (d = dv*16 + l15, g) gets keys base + g*4 + {0..3} (lo) and base + 16 + g*4 + {0..3} (hi): the same key
+    // order in which a lane's score registers sit, so P^T goes into the PV MFMA without leaving the lane
+    h8 vf[DV16][2];
+    h8 vf4[DV16];
+    const int vf_off = (g * 4 + (l15 >> 2)) * VSTR + (l15 & 3) * 4;
+#pragma unroll
+    for (int dv = 0; dv < DV16; ++dv) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const half_t* vp = &Vs[vf_off + t * 32 * VSTR + dv * 16];
+            fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
+            fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * VSTR));
+            h8 a;
+            a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
+            a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
+            vf[dv][t] = a;
+        }
+        // keys 64..79: the upper half of a third 32-key step is zero on both operands.  (The 16x16x16 MFMA would do these 16 keys
+        // in half the matrix time, but chained behind v_mfma_f32_16x16x32_f16 on the same accumulator it returned stale values in
+        // two of the four result registers on this toolchain — a missing wait state between the gfx950 and the legacy opcode.)
+        fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(&Vs[vf_off + 64 * VSTR + dv * 16]));
+        h8 b = zero8;
+        b[0] = (half_t)lo[0]; b[1] = (half_t)lo[1]; b[2] = (half_t)lo[2]; b[3] = (half_t)lo[3];
+        vf4[dv] = b;
+    }
+
+    // ---- 32 query rows per iteration and wave
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    auto load_q = [&](int q0, h8 (&qf)[2][KS]) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int qrow = q0 + qb * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int dc = ks * 32 + g * 8;
+                qf[qb][ks] = (qrow < p.Nq && dc < D) ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + dc) : zero8;
+            }
+        }
+    };
+    h8 qf[2][KS], qn[2][KS];
+    load_q(chunk * NIT * 128 + wave * 32, qf);
+    for (int it = 0; it < NIT; ++it) {
+        const int q0 = (chunk * NIT + it) * 128 + wave * 32;
+        if (q0 >= p.Nq) break;
+        // the next iteration's Q fragments are requested before this iteration's stores: loads issued after a store would wait for
+        // its write acknowledgement (one in-order vmcnt), and nothing else hides the Q latency inside a wave
+        if (it + 1 < NIT) load_q(q0 + 128, qn);
+        f4 sc[NKF][2];
+#pragma unroll
+        for (int kfi = 0; kfi < NKF; ++kfi)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                f4 a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kfi][0], qf[qb][0], z, 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < KS; ++ks) a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kfi][ks], qf[qb][ks], a, 0, 0, 0);
+                sc[kfi][qb] = a;
+            }
+#pragma unroll
+        for (int kfi = 0; kfi < NKF; ++kfi)                    // keys >= Nkv -> -inf (kfi*16 + 15 < Nkv for all but the last fragments)
+            if (kfi * 16 + 16 > p.Nkv) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kfi * 16 + g * 4 + r >= p.Nkv) sc[kfi][qb][r] = -INFINITY;
+            }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float m = max3f(sc[0][qb][0], sc[0][qb][1], sc[0][qb][2]);
+            m = max3f(m, sc[0][qb][3], sc[1][qb][0]);
+#pragma unroll
+            for (int kfi = 1; kfi < NKF; ++kfi) {
+                m = max3f(m, sc[kfi][qb][1], sc[kfi][qb][2]);
+                m = max3f(m, sc[kfi][qb][3], kfi + 1 < NKF ? sc[kfi + 1][qb][0] : sc[kfi][qb][3]);
+            }
+            const float o16 = __shfl_xor(m, 16, 64);
+            m = max3f(m, o16, o16);
+            const float o32 = __shfl_xor(m, 32, 64);
+            m = max3f(m, o32, o32);
+            const float mc = -m * c;
+            float l = 0.f;
+            union { fh2 h2v[4]; h8 v; } u0, u1;
+            union { fh2 h2v[4]; h8 v; } u2;
+            u2.v = zero8;
+#pragma unroll
+            for (int kfi = 0; kfi < NKF; ++kfi) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[kfi][qb][0], c, mc)), e1 = __builtin_amdgcn_exp2f(fmaf(sc[kfi][qb][1], c, mc));
+                const float e2 = __builtin_amdgcn_exp2f(fmaf(sc[kfi][qb][2], c, mc)), e3 = __builtin_amdgcn_exp2f(fmaf(sc[kfi][qb][3], c, mc));
+                const fh2 p01 = __builtin_amdgcn_cvt_pkrtz(e0, e1), p23 = __builtin_amdgcn_cvt_pkrtz(e2, e3);
+                // the denominator sums the SAME fp16-rounded weights that multiply V
+                l += ((float)p01[0] + (float)p01[1]) + ((float)p23[0] + (float)p23[1]);
+                if (kfi == 0) { u0.h2v[0] = p01; u0.h2v[1] = p23; }
+                else if (kfi == 1) { u0.h2v[2] = p01; u0.h2v[3] = p23; }
+                else if (kfi == 2) { u1.h2v[0] = p01; u1.h2v[1] = p23; }
+                else if (kfi == 3) { u1.h2v[2] = p01; u1.h2v[3] = p23; }
+                else { u2.h2v[0] = p01; u2.h2v[1] = p23; }
+            }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.f / l;
+            const int qrow = q0 + qb * 16 + l15;
+            half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
+#pragma unroll
+            for (int dv = 0; dv < DV16; ++dv) {
+                f4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dv][0], u0.v, z, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dv][1], u1.v, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf4[dv], u2.v, o, 0, 0, 0);
+                const int dc = dv * 16 + g * 4;
+                if (qrow < p.Nq && dc < D) {
+                    h4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[r] * inv);
+                    *reinterpret_cast<h4*>(op + dc) = ov;
+                }
+            }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[qb][ks] = qn[qb][ks];
+    }
+}
+
 template <int DPAD, int DV16, int QB>
 __global__ __launch_bounds__(256, 2) void attn_kernel_occ2(AttnParams p) {
     attn_body<DPAD, DV16, QB>(p);
@@ -807,6 +977,16 @@ int uv_launch_attention(const AttnParams& p, hipStream_t stream) {
 }
 
 static int attn_dispatch(const AttnParams& p, hipStream_t stream) {
+    // text cross-attention: one short source, K/V held in registers (attn_text_kernel).  UNIVST_ATTN_TEXT=0: generic kernels (A/B aid)
+    static const int text_env = getenv("UNIVST_ATTN_TEXT") ? atoi(getenv("UNIVST_ATTN_TEXT")) : 1;
+    if (text_env && p.nsrc == 1 && p.Nkv <= 80 && !p.src_logw && (p.d == 40 || p.d == 80) && p.Nq >= 256) {
+        const int nchunk = (p.Nq + 1023) / 1024;
+        const dim3 grid((unsigned)(nchunk * p.heads * p.BF));
+        if (p.d == 40) hipLaunchKernelGGL((attn_text_kernel<40>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attn_text_kernel<80>), grid, dim3(256), 0, stream, p);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
     switch (p.d) {
 
         case 16: return launch_attn<32, 1>(p, stream);
