@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from univst_amd import _native
 
-def run(heads, d, N, F, nsrc, B=3, iters=5):
+def run(heads, d, N, F, nsrc, B=3, iters=5, prescaled=False):
     C = heads * d
     qkv = torch.randn(B * F, N, 3 * C, device="cuda", dtype=torch.float16)
     rows = []
@@ -14,7 +14,7 @@ def run(heads, d, N, F, nsrc, B=3, iters=5):
             rows.append([prev, b * F + f, first][:nsrc] if nsrc == 3 else [prev, first])
     src = torch.tensor(rows, dtype=torch.int32, device="cuda")
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    f = lambda: _native.attention(q, k, v, src, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C)
+    f = lambda: _native.attention(q, k, v, src, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, q_prescaled=prescaled)
     f(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

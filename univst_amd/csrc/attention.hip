@@ -52,8 +52,8 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int qblk = lid % nqb;
-    const int h = (lid / nqb) % p.heads;
-    const int bf = lid / (nqb * p.heads);
+    const int h = p.order ? lid / (nqb * p.BF) : (lid / nqb) % p.heads;        // head-major block order: see attn_pp40_kernel
+    const int bf = p.order ? (lid / nqb) % p.BF : lid / (nqb * p.heads);
     constexpr int d = D;
 
     // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
@@ -362,9 +362,13 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     const int l15 = lane & 15, g = lane >> 4;
     const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // Head-major order: consecutive logical blocks (= one XCD after xcd_remap) are the query blocks of ONE head over consecutive
+    // frames.  Frame f+1 shares two of its three key sources with frame f (the clip's first frame and f itself), so their K/V
+    // lines are still in that XCD's L2; with frames outermost every (frame, head) group re-fetched all of its sources from HBM
+    // (PMC: 2.3x the compulsory bytes per launch).  AttnParams::order = 0 keeps the frame-major order (A/B aid UNIVST_ATTN_ORDER).
     const int qblk = lid % nqb;
-    const int h = (lid / nqb) % p.heads;
-    const int bf = lid / (nqb * p.heads);
+    const int h = p.order ? lid / (nqb * p.BF) : (lid / nqb) % p.heads;
+    const int bf = p.order ? (lid / nqb) % p.BF : lid / (nqb * p.heads);
     const float c = p.q_prescaled ? 1.f : p.scale_log2e;     // FOLD is only dispatched for prescaled q (c == 1)
     const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -962,7 +966,10 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
 
 static int attn_dispatch(const AttnParams& p, hipStream_t stream);
 
-int uv_launch_attention(const AttnParams& p, hipStream_t stream) {
+int uv_launch_attention(const AttnParams& p0, hipStream_t stream) {
+    static const int order_env = getenv("UNIVST_ATTN_ORDER") ? atoi(getenv("UNIVST_ATTN_ORDER")) : 1;
+    AttnParams p = p0;
+    p.order = order_env;
     UV_REQUIRE(p.d % 8 == 0, "attention: head_dim=%d must be a multiple of 8", p.d);
     UV_REQUIRE(p.nsrc >= 1 && p.Nkv >= 1 && p.Nq >= 1, "attention: empty problem");
     UV_REQUIRE(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must be multiples of 8");

@@ -58,6 +58,7 @@ struct AttnParams {
     int nsrc = 1, BF = 0, Nq = 0, Nkv = 0, heads = 0, d = 0;
     float scale_log2e = 0.f;
     int q_prescaled = 0;            // q rows already carry the factor scale_log2e (the UNet graph folds it into to_q for head_dim 40)
+    int order = 1;                  // d = 40 pipelined kernel: 1 = head-major block order (L2 reuse of shared key frames), 0 = frame-major
 };
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
