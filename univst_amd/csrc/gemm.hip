@@ -549,7 +549,25 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     const int ntiles = nt_n * ((p.M + BMB - 1) / BMB);
     const int split = lid / ntiles;                           // split-K (see gemm_kernel)
     lid -= split * ntiles;
-    const int tn = lid % nt_n, tm = lid / nt_n;
+    // Tile order.  The ~32 tiles an XCD runs at a time should share operands that fit its 4 MB L2.  With the column tile as the
+    // fastest index and MANY column tiles (GEGLU / QKV projections of the 32x32 and 16x16 levels: 6 .. 32 of them, weights of 6 - 26
+    // MB), 32 concurrent tiles are 1 - 2 row tiles x all of W: W streams from HBM once per pair of row tiles (1.7 GB per launch of
+    // the 32x32-level GEGLU projection).  p.tile_gn > 0: groups of tile_gm row tiles x tile_gn column tiles; the column blocks of
+    // one row group run back to back (its activation rows stay in L2), W is read once per row group.  Measured: -2..4 % on the
+    // GEGLU / QKV projections of the 32x32 and 16x16 levels — they were closer to the matrix pipe's limit than to the memory's.
+    int tn, tm;
+    if (p.tile_gn > 0) {
+        const int nt_m = ntiles / nt_n;
+        const int mg = lid / (p.tile_gm * nt_n);                          // row group
+        const int gm = nt_m - mg * p.tile_gm < p.tile_gm ? nt_m - mg * p.tile_gm : p.tile_gm;      // its height (the last one may be short)
+        const int rem = lid - mg * p.tile_gm * nt_n;
+        const int nb = rem / (gm * p.tile_gn), r2 = rem - nb * gm * p.tile_gn;
+        tm = mg * p.tile_gm + r2 % gm;
+        tn = nb * p.tile_gn + r2 / gm;
+    } else {
+        tn = lid % nt_n;
+        tm = lid / nt_n;
+    }
     const int m0 = tm * BMB, n0 = tn * BNB;
     const int nk_all = (p.K + BK - 1) / BK;
     const int kt0 = p.splits > 1 ? split * p.ktps : 0;
@@ -1032,6 +1050,16 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             static const int epi = getenv("UNIVST_GEMM_EPI") ? atoi(getenv("UNIVST_GEMM_EPI")) : 1;
             auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
             GemmParams q = p;
+            {   // row-group x column-block tile order for wide outputs (see gemm_big_kernel); UNIVST_GEMM_TILEORDER=0: column-fastest
+                static const int to_env = getenv("UNIVST_GEMM_TILEORDER") ? atoi(getenv("UNIVST_GEMM_TILEORDER")) : 1;
+                const int ntn = p.N / 320;
+                q.tile_gn = 0;
+                if (to_env && mode == 0 && ntn > 4 && (long)p.N * p.K * 2 > (3L << 20)) {      // W larger than ~3 MB: it cannot stay in L2 as a whole
+                    q.tile_gn = ntn % 2 == 0 ? 2 : 0;       // 8 x 2 measured best of 8x4 / 16x2 / 4x8 / 16x4 / 32x4 (all within 2 %); 10 x 3 was a loss
+                    q.tile_gm = 8;
+                    if (to_env > 1) { q.tile_gn = to_env % 100; q.tile_gm = to_env / 100; if (ntn % q.tile_gn) q.tile_gn = 0; }    // A/B: gm*100 + gn
+                }
+            }
             // next tile's DMA: activation rows before the first k-half's MFMAs, weight rows before the second (1, default; +2..8 % on
             // the linears: the LDS-DMA writes at 64 B/clk and competes with the fragment reads) or all at once (0)
             static const int issue_mode = getenv("UNIVST_GEMM_ISSUE") ? atoi(getenv("UNIVST_GEMM_ISSUE")) : 1;

@@ -32,6 +32,7 @@ struct GemmParams {
     float* partial = nullptr;          // caller-provided workspace (UNet arena) or null (the launcher then uses hipMallocAsync)
     size_t partial_bytes = 0;
     int splits = 1, ktps = 0;          // set by the launcher
+    int tile_gn = 0, tile_gm = 0;      // 256x320 kernel: tile order in groups of tile_gm row tiles x tile_gn column tiles (0: column tile fastest); set by the launcher
     int issue_mode = 0;                // 256x320 kernel, A/B aid: how the next tile's DMA is spread over the current tile's MFMAs
     // LayerNorm folded into the linears around it (256x320 direct path only, uv_linear_takes_big_direct):
     //  producer: stats_out[m][N/160][2] <- (sum, sum of squares) of the stored fp16 outputs per 160-column slot;
