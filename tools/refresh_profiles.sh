@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/raw/fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/raw/write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/raw/write.log 2>&1
 bash tools/pmc_attn.sh $O/raw/attn > $O/round${ROUND}_pmc_attn_d40_sq.txt 2>&1
 bash tools/pmc_gemm.sh $O/raw/gemm convp 2>&1 | grep -E "^SQ_" > $O/round${ROUND}_pmc_conv_patch_sq.txt
-for w in inversion maskprop warp; do python bench.py --workload $w --no-cpu-baseline > $O/round${ROUND}_bench_$w.json 2>> $O/raw/bench.err; done
+for w in inversion inversion_pair transfer_nomask maskprop warp; do python bench.py --workload $w --no-cpu-baseline > $O/round${ROUND}_bench_$w.json 2>> $O/raw/bench.err; done
 python bench.py --frames 32 --emulate-rank 0/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank0of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 7/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank7of8.json 2>> $O/raw/bench.err
