@@ -1,0 +1,58 @@
+"""The drop-in surface of INTEGRATION.md level 1: with this repository first on the path, the reference's import paths resolve to
+the native implementation and expose the names the reference's scripts use (reference files cited per entry).  CPU only: nothing is
+computed, the modules are imported and their public names compared with the package they re-export."""
+import importlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SURFACE = {
+    # reference module path -> (product module, names the reference's callers import from it)
+    "backbones.video_diffusion_sd.pnp_utils": ("univst_amd.backbones.video_diffusion_sd.pnp_utils",
+                                               ["register_time", "register_spatial_attention_pnp", "attention_adain", "latent_adain"]),      # pnp_utils.py:7,18,114,128
+    "backbones.video_diffusion_sd.models.unet_3d_condition": ("univst_amd.backbones.video_diffusion_sd.models.unet_3d_condition",
+                                                              ["UNetPseudo3DConditionModel"]),                                              # unet_3d_condition.py:37
+    "backbones.video_diffusion_sd.pipelines.stable_diffusion": ("univst_amd.backbones.video_diffusion_sd.pipelines.stable_diffusion",
+                                                                ["SpatioTemporalStableDiffusionPipeline"]),                                 # stable_diffusion.py:45
+    "inversion_tools.ddim_inversion": ("univst_amd.inversion_tools.ddim_inversion",
+                                       ["ddim_inversion", "ddim_loop", "ddim_loop_plus", "next_step", "content_inversion_reconstruction",
+                                        "style_inversion_reconstruction", "load_video_frames"]),                                           # ddim_inversion.py:16-212
+    "src.util": ("univst_amd.src.util", ["load_ddim_latents_at_t", "load_mask", "save_folder", "save_videos_grid", "save_images_as_mp4",
+                                         "load_image", "seed_everything"]),                                                                # util.py
+    "src.mask_propagation": ("univst_amd.src.mask_propagation", ["video_mask_propogation", "mask_propogation", "read_feature", "norm_mask",
+                                                                 "to_one_hot"]),                                                            # mask_propagation.py:15-140
+    "src.cal_optica_flow": ("univst_amd.src.cal_optica_flow", ["get_warp"]),                                                               # cal_optica_flow.py:51
+}
+
+
+@pytest.mark.parametrize("ref_path", sorted(SURFACE))
+def test_reference_import_paths_resolve_to_the_native_package(ref_path):
+    prod_path, names = SURFACE[ref_path]
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    shim, prod = importlib.import_module(ref_path), importlib.import_module(prod_path)
+    assert os.path.abspath(shim.__file__).startswith(ROOT), f"{ref_path} resolved outside this repository: {shim.__file__}"
+    for n in names:
+        assert hasattr(prod, n), f"{prod_path} lacks {n}"
+        assert getattr(shim, n) is getattr(prod, n), f"{ref_path}.{n} is not the native implementation's"
+
+
+@pytest.mark.parametrize("script", ["run_content_inversion_sd", "run_style_inversion_sd", "run_video_style_transfer_sd"])
+def test_cli_scripts_keep_the_reference_flags(script):
+    """src/sd/run_*_sd.py --help works without a GPU and lists the reference's flags (run_*_sd.py argparse blocks)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "src", "sd", script + ".py"), "--help"], capture_output=True, text=True,
+                         cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    # the argparse blocks of the reference's three scripts (src/sd/run_*_sd.py)
+    want = {"run_content_inversion_sd": ["--pretrained_model_path", "--content_path", "--output_path", "--weight_dtype", "--num_frames", "--height",
+                                         "--width", "--time_steps", "--ft_indices", "--ft_timesteps", "--is_opt", "--seed"],
+            "run_style_inversion_sd": ["--pretrained_model_path", "--style_path", "--output_path", "--weight_dtype", "--num_frames", "--height",
+                                       "--width", "--time_steps", "--is_opt", "--seed"],
+            "run_video_style_transfer_sd": ["--pretrained_model_path", "--content_inv_path", "--style_inv_path", "--mask_path", "--output_path",
+                                            "--weight_dtype", "--time_steps", "--seed"]}[script]
+    for flag in want:
+        assert flag in out.stdout, f"{script}: flag {flag} missing from --help"
