@@ -1,0 +1,139 @@
+"""Oracle groundwork for SURVEY §8f-4 (SD3 / SD3.5 rectified-flow backbone): the REFERENCE-OWNED pieces of that path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Nothing in univst_amd/ implements this path yet: this file and the goldens
+G15-G17 are the "oracle + goldens first" step the round-1 verdict prescribes for config 5, so that a HIP path built later has a
+pinned target.  Restated here (each function cites what it follows):
+
+  * attention_adain / latent_adain of the SD3 plugin          backbones/video_diffusion_sd3/pnp_utils.py:287-316
+  * the cross-frame key/value gather ['first', -1, 0]          pnp_utils.py:27,53-78
+  * CrossFrameProcessor / AttentionShiftProcessor              pnp_utils.py:9-131 / :134-271
+  * rf_inversion / rf_solver                                   inversion_tools/flow_inversion.py:123-264
+
+The reference is BROKEN at HEAD on this path: AttentionShiftProcessor reads an attribute `self.thresh2` that is
+never set (pnp_utils.py:186).  The documented FIXED READING used here and by the golden generator is thresh2 == eta2 (the only
+value that makes beta run from 0.9 at eta1*50 to 0.1 at eta2*50, like the SD-v1.5 closure, pnp_utils.py:49-50 of that plugin);
+the generator sets that attribute on the processor instance before calling the reference's own __call__ — no reference code is
+edited or copied.  The MM-DiT backbone itself (diffusers SD3Transformer2DModel: patch embedding, adaLN, the joint transformer
+blocks around these processors) and the FlowMatchEuler sigma schedule are third-party and absent: parity unpinned for those.
+"""
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+def attention_adain(cnt: torch.Tensor, sty: torch.Tensor) -> torch.Tensor:
+    """pnp_utils.py:287-300 on [B, heads, N, d]: style mean / (unbiased) std over the token axis, applied to
+    F.instance_norm(cnt) — which on a 4-D tensor treats dim 1 (heads) as channels and normalises over (N, d) JOINTLY with the
+    biased variance and eps 1e-5 (the same layout quirk as the SD-v1.5 plugin)."""
+    sty_mean = sty.mean(dim=[-2], keepdim=True)
+    sty_std = sty.std(dim=[-2], keepdim=True)
+    mu = cnt.mean(dim=(2, 3), keepdim=True)
+    var = cnt.var(dim=(2, 3), keepdim=True, unbiased=False)
+    return ((cnt - mu) / torch.sqrt(var + 1e-5) * sty_std + sty_mean).to(cnt.dtype)
+
+
+def latent_adain(cnt: torch.Tensor, sty: torch.Tensor) -> torch.Tensor:
+    """pnp_utils.py:303-316 on [B, C, H, W] (frames are the batch): per (frame, channel) statistics over (H, W)."""
+    sty_mean = sty.mean(dim=[2, 3], keepdim=True)
+    sty_std = sty.std(dim=[2, 3], keepdim=True)
+    mu = cnt.mean(dim=(2, 3), keepdim=True)
+    var = cnt.var(dim=(2, 3), keepdim=True, unbiased=False)
+    return ((cnt - mu) / torch.sqrt(var + 1e-5) * sty_std + sty_mean).to(cnt.dtype)
+
+
+def cross_frame_gather(x: torch.Tensor, clip_length: int = 16) -> torch.Tensor:
+    """pnp_utils.py:53-78: x [(b f), heads, N, d] -> [(b f), heads, 3N, d], the tokens of frames ['first', f-1 (clipped), f] of the
+    same clip concatenated along the token axis."""
+    bf, hh, n, d = x.shape
+    xb = x.view(bf // clip_length, clip_length, hh, n, d)
+    first = torch.zeros(clip_length, dtype=torch.long)
+    prev = (torch.arange(clip_length) - 1).clip(0, clip_length - 1)
+    cur = torch.arange(clip_length)
+    out = torch.cat([xb[:, first], xb[:, prev], xb[:, cur]], dim=-2)
+    return out.reshape(bf, hh, 3 * n, d)
+
+
+def _rms(x: torch.Tensor, w: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    """diffusers RMSNorm over the head dim (SD3.5 qk_norm="rms_norm"): x * rsqrt(mean(x^2) + eps) * weight."""
+    if w is None:
+        return x
+    return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * w
+
+
+def joint_attention(P: Dict[str, torch.Tensor], heads: int, hidden: torch.Tensor, enc: Optional[torch.Tensor], idx: int = -1,
+                    shift: bool = False, eta1: float = 0.0, eta2: float = 0.6, clip_length: int = 16, rms_eps: float = 1e-6,
+                    context_pre_only: bool = False):
+    """CrossFrameProcessor (shift=False, pnp_utils.py:17-131) / AttentionShiftProcessor (shift=True, :143-271, fixed reading
+    thresh2 == eta2).  P holds the attention module's parameters: to_{q,k,v}.{weight,bias}, norm_{q,k}.weight, add_{q,k,v}_proj.*,
+    norm_added_{q,k}.weight, to_out.0.*, to_add_out.*.  hidden [(3 f) or (b f), N, C]; enc [(b f), Nt, C] or None."""
+    lin = lambda x, n: F.linear(x, P[n + ".weight"], P.get(n + ".bias"))
+    B = hidden.shape[0]
+    q, k, v = lin(hidden, "to_q"), lin(hidden, "to_k"), lin(hidden, "to_v")
+    d = k.shape[-1] // heads
+    sp = lambda t: t.view(B, -1, heads, d).transpose(1, 2)
+    q, k, v = sp(q), sp(k), sp(v)
+    q = _rms(q, P.get("norm_q.weight"), rms_eps)
+    k = _rms(k, P.get("norm_k.weight"), rms_eps)
+    if shift:
+        c = B // 3
+        if idx >= eta1 * 50 and idx <= eta2 * 50:          # pnp_utils.py:183-194 (alpha 0.8, gamma 2.0)
+            alpha, gamma = 0.8, 2.0
+            beta = (0.9 - 0.1) / (eta1 * 50 - eta2 * 50) * (idx - eta2 * 50) + 0.1
+            q, k, v = q.clone(), k.clone(), v.clone()
+            q[2 * c:3 * c] = alpha * q[:c] + (1 - alpha) * q[2 * c:3 * c]
+            k[2 * c:3 * c] = beta * attention_adain(k[2 * c:3 * c], k[c:2 * c]) + (1 - beta) * k[c:2 * c]
+            v[2 * c:3 * c] = beta * attention_adain(v[2 * c:3 * c], v[c:2 * c]) + (1 - beta) * v[c:2 * c]
+            q[2 * c:3 * c] = gamma * q[2 * c:3 * c]
+    k = cross_frame_gather(k, clip_length)
+    v = cross_frame_gather(v, clip_length)
+    if enc is not None:
+        eq, ek, ev = sp(lin(enc, "add_q_proj")), sp(lin(enc, "add_k_proj")), sp(lin(enc, "add_v_proj"))
+        eq = _rms(eq, P.get("norm_added_q.weight"), rms_eps)
+        ek = _rms(ek, P.get("norm_added_k.weight"), rms_eps)
+        q, k, v = torch.cat([q, eq], dim=2), torch.cat([k, ek], dim=2), torch.cat([v, ev], dim=2)
+    o = F.scaled_dot_product_attention(q, k, v)
+    o = o.transpose(1, 2).reshape(B, -1, heads * d)
+    n_img = hidden.shape[1]
+    if enc is not None:
+        o, eo = o[:, :n_img], o[:, n_img:]
+        if not context_pre_only:
+            eo = lin(eo, "to_add_out")
+        return lin(o, "to_out.0"), eo
+    return lin(o, "to_out.0")
+
+
+def rf_inversion(velocity_fn: Callable, latents: torch.Tensor, sigmas: torch.Tensor, target_noise: torch.Tensor, gamma: float = 0.5) -> List[torch.Tensor]:
+    """flow_inversion.py:123-188: controlled forward ODE towards `target_noise`; sigmas as the scheduler gives them (decreasing,
+    last 0) — the loop runs them flipped, t from 0 to 1.  velocity_fn(x, t_scaled_by_1000, idx) -> v.  Returns the trajectory."""
+    ts = torch.flip(sigmas, dims=[0])
+    traj = [latents.clone()]
+    for idx, (t_curr, t_prev) in enumerate(zip(ts[:-1], ts[1:])):
+        pred = velocity_fn(latents, t_curr * 1000, idx)
+        target_v = (target_noise - latents) / (1.0 - t_curr)
+        v = gamma * target_v + (1 - gamma) * pred
+        latents = latents + (t_prev - t_curr) * v
+        traj.append(latents.clone())
+    return traj
+
+
+def rf_solver(velocity_fn: Callable, latents: torch.Tensor, sigmas: torch.Tensor) -> List[torch.Tensor]:
+    """flow_inversion.py:191-264: second-order (midpoint-derivative) inversion: x += dt v + dt^2/2 * (v_mid - v) / (dt/2)."""
+    ts = torch.flip(sigmas, dims=[0])
+    traj = [latents.clone()]
+    for idx, (t_curr, t_prev) in enumerate(zip(ts[:-1], ts[1:])):
+        pred = velocity_fn(latents, 1000 * t_curr, idx)
+        mid = latents + (t_prev - t_curr) / 2 * pred
+        pred_mid = velocity_fn(mid, 1000 * (t_curr + (t_prev - t_curr) / 2), idx)
+        first_order = (pred_mid - pred) / ((t_prev - t_curr) / 2)
+        latents = latents + (t_prev - t_curr) * pred + 0.5 * (t_prev - t_curr) ** 2 * first_order
+        traj.append(latents.clone())
+    return traj
+
+
+def flow_match_sigmas(n: int, shift: float = 3.0, num_train_timesteps: int = 1000) -> torch.Tensor:
+    """diffusers 0.35.1 FlowMatchEulerDiscreteScheduler.set_timesteps(n) with the SD3 config (shift 3.0, no dynamic shifting):
+    sigma = shift*s / (1 + (shift-1)*s) on s = linspace(1, 1/T, n), then a trailing 0.  Third-party, parity unpinned."""
+    s = torch.linspace(1.0, 1.0 / num_train_timesteps, n, dtype=torch.float32)
+    sig = shift * s / (1 + (shift - 1) * s)
+    return torch.cat([sig, torch.zeros(1)])

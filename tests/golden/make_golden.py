@@ -476,6 +476,102 @@ def main():
         g14[tag] = {f"i{i}": cap[i] for i in keep_r}
     gold["g14_reconstruction"] = g14
 
+    # ---- G15 / G16 / G17: the reference-owned pieces of the SD3 / SD3.5 path (oracle groundwork only — no HIP path
+    #      yet).  The SD3 plugin is imported from the reference; its processors run on a local stand-in for diffusers' Attention
+    #      MODULE (parameters only: the arithmetic is the reference's __call__).  AttentionShiftProcessor reads `self.thresh2`, which
+    #      the reference never sets (pnp_utils.py:186): the documented fixed reading thresh2 == eta2 is set on the instance.
+    from oracle import sd3_ref
+    from backbones.video_diffusion_sd3 import pnp_utils as ref_sd3
+    g = torch.Generator().manual_seed(1501)
+    k1, k2 = torch.randn(16, 2, 12, 8, generator=g), 0.4 + 1.7 * torch.randn(16, 2, 12, 8, generator=g)
+    gold["g15_sd3_attention_adain"] = dict(cnt=k1, sty=k2, out=ref_sd3.attention_adain(k1, k2))
+    chk("sd3_attention_adain", gold["g15_sd3_attention_adain"]["out"], sd3_ref.attention_adain(k1, k2))
+    l1, l2 = torch.randn(16, 4, 6, 6, generator=g), -0.2 + 0.6 * torch.randn(16, 4, 6, 6, generator=g)
+    gold["g15_sd3_latent_adain"] = dict(cnt=l1, sty=l2, out=ref_sd3.latent_adain(l1, l2))
+    chk("sd3_latent_adain", gold["g15_sd3_latent_adain"]["out"], sd3_ref.latent_adain(l1, l2))
+
+    class JointAttn(torch.nn.Module):        # the attributes the reference's processors read from diffusers' Attention (SD3.5: qk rms norm)
+        def __init__(self, dim=16, heads=2, dim_head=8):
+            super().__init__()
+            inner = heads * dim_head
+            self.heads, self.context_pre_only = heads, False
+            self.to_q, self.to_k, self.to_v = (torch.nn.Linear(dim, inner) for _ in range(3))
+            self.add_q_proj, self.add_k_proj, self.add_v_proj = (torch.nn.Linear(dim, inner) for _ in range(3))
+            self.norm_q, self.norm_k = torch.nn.RMSNorm(dim_head, eps=1e-6), torch.nn.RMSNorm(dim_head, eps=1e-6)
+            self.norm_added_q, self.norm_added_k = torch.nn.RMSNorm(dim_head, eps=1e-6), torch.nn.RMSNorm(dim_head, eps=1e-6)
+            self.to_out = torch.nn.ModuleList([torch.nn.Linear(inner, dim), torch.nn.Dropout(0.0)])
+            self.to_add_out = torch.nn.Linear(inner, dim)
+
+    attn = JointAttn()
+    gg = torch.Generator().manual_seed(1601)
+    for prm in attn.parameters():
+        prm.data = torch.randn(prm.shape, generator=gg) * (0.3 if prm.dim() > 1 else 0.2) + (1.0 if prm.dim() == 1 and prm.shape[0] == 8 else 0.0)
+    attn.eval()
+    Psd3 = {kk: vv.clone() for kk, vv in attn.state_dict().items()}
+    hid = torch.randn(48, 9, 16, generator=gg)           # 3 branches x 16 frames (the processors hard-code clip_length = 16), 9 image tokens
+    enc = torch.randn(48, 5, 16, generator=gg)           # 5 text tokens
+    g16 = dict(params=Psd3, hidden=hid, enc=enc)
+    with torch.no_grad():
+        o_img, o_txt = ref_sd3.CrossFrameProcessor()(attn, hid.clone(), enc.clone())
+        m_img, m_txt = sd3_ref.joint_attention(Psd3, 2, hid, enc)
+        chk("sd3_cross_frame_processor_img", o_img, m_img)
+        chk("sd3_cross_frame_processor_txt", o_txt, m_txt)
+        g16["cross_frame"] = dict(img=o_img, txt=o_txt)
+        o_self = ref_sd3.CrossFrameProcessor()(attn, hid.clone())
+        chk("sd3_cross_frame_processor_no_text", o_self, sd3_ref.joint_attention(Psd3, 2, hid, None))
+        g16["cross_frame_no_text"] = o_self
+        for idx in (0, 17, 30, 31):                      # window eta1*50 = 0 .. eta2*50 = 30
+            proc = ref_sd3.AttentionShiftProcessor(0.0, 0.6)
+            proc.thresh2 = proc.eta2                     # the fixed reading (see the module docstring of oracle/sd3_ref.py)
+            o_img, o_txt = proc(attn, hid.clone(), enc.clone(), idx=idx)
+            m_img, m_txt = sd3_ref.joint_attention(Psd3, 2, hid, enc, idx=idx, shift=True, eta1=0.0, eta2=0.6)
+            chk(f"sd3_attention_shift_idx{idx}_img", o_img, m_img)
+            chk(f"sd3_attention_shift_idx{idx}_txt", o_txt, m_txt)
+            g16[f"shift_idx{idx}"] = dict(img=o_img, txt=o_txt)
+    assert not torch.equal(g16["shift_idx30"]["img"], g16["cross_frame"]["img"]) and torch.equal(g16["shift_idx31"]["img"], g16["cross_frame"]["img"])
+    gold["g16_sd3_processors"] = g16
+
+    #      rf_inversion / rf_solver (inversion_tools/flow_inversion.py:123-264) over a stand-in pipeline: a closed-form velocity
+    #      field as the transformer, the SD3 flow-match sigma schedule restated in oracle/sd3_ref.flow_match_sigmas (third-party)
+    sys.modules["diffusers.utils"].export_to_video = lambda *a, **k: None
+    from inversion_tools import flow_inversion as ref_flow
+    n_rf = 10
+    sig = sd3_ref.flow_match_sigmas(n_rf)
+
+    def vel(x, t1000, idx):
+        tt = (t1000 / 1000.0).reshape(-1)[0]
+        return torch.tanh(0.7 * x.flip(-1)) * (0.5 + tt) - 0.3 * x + 0.05 * idx
+
+    class _Bar:
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def update(self): pass
+
+    class RFPipe:
+        device = "cpu"
+        scheduler = types.SimpleNamespace(sigmas=sig, set_timesteps=lambda n, device=None: None)
+        def encode_prompt(self, prompt, prompt_2, prompt_3): return (torch.zeros(1, 4, 8), None, torch.zeros(1, 8), None)
+        def progress_bar(self, total=None): return _Bar()
+        def transformer(self, hidden_states, timestep, encoder_hidden_states, pooled_projections, idx=0, ft_indices=None, ft_timesteps=None,
+                        ft_path=None, return_dict=False):
+            return (vel(hidden_states, timestep, idx),)
+
+    z0 = torch.randn(16, 4, 6, 6, generator=gg)
+    g17 = dict(sigmas=sig, z0=z0)
+    with torch.no_grad():
+        torch.manual_seed(1701)
+        zT = ref_flow.rf_inversion(RFPipe(), z0.clone(), gamma=0.5, num_inference_steps=n_rf)
+        torch.manual_seed(1701)
+        noise = torch.randn_like(z0)
+        mine = sd3_ref.rf_inversion(vel, z0.clone(), sig, noise, 0.5)
+        chk("sd3_rf_inversion_final", zT, mine[-1])
+        g17["rf_inversion"] = dict(noise=noise, final=zT)
+        zS = ref_flow.rf_solver(RFPipe(), z0.clone(), num_inference_steps=n_rf)
+        mine = sd3_ref.rf_solver(vel, z0.clone(), sig)
+        chk("sd3_rf_solver_final", zS, mine[-1])
+        g17["rf_solver"] = dict(final=zS)
+    gold["g17_sd3_rf"] = g17
+
     for k, v in gold.items():
         torch.save(v, os.path.join(OUT, k + ".pt"))
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:

@@ -262,3 +262,47 @@ def test_product_scheduler_step_matches_g7(golden):
     for i, t in enumerate(g["timesteps"]):
         out = s.step(g["e"], int(t), g["z"])
         assert torch.equal(out.prev_sample, g["prev"][i]), int(t)
+
+
+# ---- SURVEY §8f-4 groundwork: the reference-owned pieces of the SD3 / SD3.5 path (oracle/sd3_ref.py; no HIP path exists yet)
+def test_sd3_adains(golden):
+    from oracle import sd3_ref
+    a = golden("g15_sd3_attention_adain")
+    assert rel(sd3_ref.attention_adain(a["cnt"], a["sty"]), a["out"]) < TOL
+    b = golden("g15_sd3_latent_adain")
+    assert rel(sd3_ref.latent_adain(b["cnt"], b["sty"]), b["out"]) < TOL
+
+
+def test_sd3_joint_attention_processors(golden):
+    """CrossFrameProcessor and AttentionShiftProcessor of the reference's SD3 plugin (the latter under the documented fixed reading
+    thresh2 == eta2) on 3 branches x 16 frames, 9 image + 5 text tokens, inside and outside the shift window."""
+    from oracle import sd3_ref
+    g = golden("g16_sd3_processors")
+    P, hid, enc = g["params"], g["hidden"], g["enc"]
+    img, txt = sd3_ref.joint_attention(P, 2, hid, enc)
+    assert rel(img, g["cross_frame"]["img"]) < TOL and rel(txt, g["cross_frame"]["txt"]) < TOL
+    assert rel(sd3_ref.joint_attention(P, 2, hid, None), g["cross_frame_no_text"]) < TOL
+    for idx in (0, 17, 30, 31):
+        img, txt = sd3_ref.joint_attention(P, 2, hid, enc, idx=idx, shift=True, eta1=0.0, eta2=0.6)
+        assert rel(img, g[f"shift_idx{idx}"]["img"]) < TOL and rel(txt, g[f"shift_idx{idx}"]["txt"]) < TOL, idx
+    # the first two branches never change; the third does inside the window only
+    img30, _ = sd3_ref.joint_attention(P, 2, hid, enc, idx=30, shift=True)
+    plain, _ = sd3_ref.joint_attention(P, 2, hid, enc)
+    assert torch.equal(img30[:32], plain[:32]) and not torch.equal(img30[32:], plain[32:])
+    # cross-frame gather: frame f reads ['first', f-1, f] of its own clip
+    x = torch.arange(48.0).view(48, 1, 1, 1).expand(48, 1, 2, 1)
+    got = sd3_ref.cross_frame_gather(x)[:, 0, ::2, 0]
+    assert got[0].tolist() == [0, 0, 0] and got[5].tolist() == [0, 4, 5] and got[16].tolist() == [16, 16, 16] and got[47].tolist() == [32, 46, 47]
+
+
+def test_sd3_rectified_flow_inversions(golden):
+    from oracle import sd3_ref
+    g = golden("g17_sd3_rf")
+    sig, z0 = g["sigmas"], g["z0"]
+    assert torch.equal(sig, sd3_ref.flow_match_sigmas(10)) and sig[-1] == 0 and bool((sig[:-1] > sig[1:]).all())
+
+    def vel(x, t1000, idx):
+        tt = (t1000 / 1000.0).reshape(-1)[0]
+        return torch.tanh(0.7 * x.flip(-1)) * (0.5 + tt) - 0.3 * x + 0.05 * idx
+    assert rel(sd3_ref.rf_inversion(vel, z0.clone(), sig, g["rf_inversion"]["noise"], 0.5)[-1], g["rf_inversion"]["final"]) < TOL
+    assert rel(sd3_ref.rf_solver(vel, z0.clone(), sig)[-1], g["rf_solver"]["final"]) < TOL
