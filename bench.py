@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py — stylized frames/sec of the UniVST SD-v1.5 three-branch denoising loop on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N>1: one rank per GPU — launched by torch.distributed.run, or,
+                                                                    when no launcher environment is present, re-executed under it)
 
 Workload (BASELINE.json metric): SD-v1.5 geometry UNet (random-init synthetic weights of that architecture,
 fp16), 16 frames x 512x512 (latents [1,4,16,64,64]), 50 DDIM steps of the three-branch transfer loop
@@ -51,6 +52,8 @@ def parse():
                                                                             "(Linear projections, head_dim 64, 1024-wide text states; SURVEY §8f-3)")
     ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
                                                              "(no extrapolation in F; ~2 min on 16 threads) instead of F=2")
+    ap.add_argument("--selftest-launch", action="store_true", help="multi-rank plumbing only (rendezvous, barriers, MAX over ranks, one JSON "
+                                                                    "line); no GPU work, runs on a CPU box with --backend gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-skip-dead-branches-leg", action="store_true",
@@ -212,8 +215,53 @@ def run_aux_workload(a, dev):
     return out
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher environment: re-execute this command under torch.distributed.run with one rank per
+    GPU (exactly what the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` does), so the
+    line printed has n_gpus = N either way.  Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL / cross-process device memory)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_selftest(a, rank, world):
+    """--selftest-launch: everything of a multi-rank run except the GPU work — rendezvous, barrier-bracketed timing of K empty steps,
+    MAX over ranks, one JSON line from rank 0 with n_gpus = world.  Runs on a CPU-only box (gloo); tests/test_bench_launch.py."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(a.backend if a.backend != "nccl" or torch.cuda.is_available() else "gloo", timeout=datetime.timedelta(seconds=120))
+    for _ in range(a.warmup):
+        pass
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001 * (1 + rank))           # ranks differ: the reported time must be the slowest rank's
+    dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "launch selftest (no GPU work)", "value": None, "unit": "frames/s", "n_gpus": world, "steps": a.steps,
+                          "warmup": a.warmup, "ms_per_step": round(dt.item() / a.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "none",
+                          "config": {"workload": "selftest_launch", "parallelism": f"frames{world}", "backend": dist.get_backend()}}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.emulate_rank:
+        sys.exit(self_launch(a))
+    if a.selftest_launch:
+        return launch_selftest(a, int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -366,7 +414,7 @@ def main():
             import re
             # class label -> the kernel symbols it times (template arguments as rocprofv3 prints them; tools/summarize_profiles.py uses the same map)
             pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
-                   "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0>"}.get(dom, re.escape(dom.replace(" ", "")))
+                   "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0[,>]"}.get(dom, re.escape(dom.replace(" ", "")))
             hit = [v for k, v in pm.items() if re.search(pat, k.replace(" ", ""))]
             if hit and world == 1:      # a class may span several symbols (the 256- and 192-row tile): launch-weighted mean
                 nl = sum(v["launches_sampled"] for v in hit)

@@ -47,7 +47,7 @@ try:
     import re
     # bench.py class label -> the kernel symbols it times (template arguments as rocprofv3 prints them)
     pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
-           "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0>", "attn_kernel_occ3<96,5,2>": r"attn_kernel_occ3<96,5,2>"}.get(dom, re.escape(dom.replace(" ", "")))
+           "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0[,>]", "attn_kernel_occ3<96,5,2>": r"attn_kernel_occ3<96,5,2>"}.get(dom, re.escape(dom.replace(" ", "")))
     rows = [r for r in csv.DictReader(open(ks)) if re.search(pat, r["Name"].replace(" ", ""))]
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)
     open(os.path.join(O, f"round{RND}_agreement.txt"), "w").write(

@@ -347,6 +347,8 @@ class UNetPseudo3DConditionModel(nn.Module):
         if self.device.type != "cuda":
             raise RuntimeError("UNetPseudo3DConditionModel.forward runs only on an AMD GPU: call .cuda() first "
                                "(univst_amd has no CPU path)")
+        if self._native_handle is not None and os.environ.get("UNIVST_STRICT_WEIGHTS") == "1":
+            self.verify_native_weights()
         fp = self._weights_fingerprint()
         if self._native_handle is not None and not self._native_dirty and fp == self._native_fp:
             return
@@ -376,17 +378,42 @@ class UNetPseudo3DConditionModel(nn.Module):
         for k, v in getattr(self, "_native_options", {}).items():
             _native.check(lib.univst_unet_set_option(h, k.encode(), int(v)), f"unet_set_option({k})")
         self._native_handle = h
+        self._native_sum = self._content_checksum()
         self._native_dirty = False
         self._native_fp = fp
 
     def _weights_fingerprint(self):
-        """(storage address, in-place version counter) of every parameter / buffer: the native copy (incl. the derived fused
-        QKV, tap-inner conv and stacked time_emb_proj tensors) is rebuilt when any of them was edited in place
-        (``p.data.copy_``, LoRA merges, optimizer steps ...) or re-allocated, not only on ``_apply`` / ``load_state_dict``."""
+        """(storage address, autograd version counter) of every parameter / buffer, over a tensor list cached until the next
+        ``_apply`` / ``load_state_dict``.  The native copy (incl. the derived fused QKV, tap-inner conv, LayerNorm-folded and stacked
+        time_emb_proj tensors) is rebuilt when a tensor was re-allocated or edited in place THROUGH THE TENSOR ITSELF (``p.copy_``,
+        ``p.add_`` under ``no_grad``, optimizer steps): those bump ``p._version``.  Edits through ``p.data`` (``p.data.copy_``,
+        ``w.data += delta`` — the usual LoRA-merge idiom) carry their own version counter and are NOT seen here: call
+        ``invalidate_native()`` after them, or ``verify_native_weights()`` (one device checksum + a sync) to find out; setting
+        ``UNIVST_STRICT_WEIGHTS=1`` runs that check before every forward."""
+        ts = self.__dict__.get("_native_tensors")
+        n = self.__dict__["_native_fp_calls"] = self.__dict__.get("_native_fp_calls", 0) + 1
+        if ts is None or self._native_dirty or n % 64 == 0:      # (a Parameter object swapped on a submodule shows up at the next refresh)
+            ts = self._native_tensors = list(self.state_dict(keep_vars=True).values())
         acc = 0
-        for t in self.state_dict(keep_vars=True).values():
+        for t in ts:
             acc = (acc * 1000003 + t.data_ptr() + 7919 * t._version) & 0xFFFFFFFFFFFFFFFF
         return acc
+
+    def _content_checksum(self):
+        """per-tensor fp64 sums of the CURRENT parameter values, one device tensor (no sync here)."""
+        return torch.stack([t.detach().sum(dtype=torch.float64) for t in self.state_dict(keep_vars=True).values()])
+
+    def verify_native_weights(self) -> bool:
+        """True when the native weight copy still matches the module's parameters by content (catches ``p.data`` edits the
+        fingerprint cannot see); on a mismatch the copy is marked stale and rebuilt by the next forward.  Costs one pass over the
+        weights and a host sync: a debugging / safety aid, not part of the per-step path."""
+        ref = self.__dict__.get("_native_sum")
+        if self._native_handle is None or ref is None:
+            return False
+        ok = bool(torch.equal(self._content_checksum(), ref))
+        if not ok:
+            self._native_dirty = True
+        return ok
 
     def set_native_option(self, name: str, value: int):
         """tuning switch of the native graph (include/univst.h ``univst_unet_set_option``), e.g. ``("ln_fold", 0)``; survives rebuilds."""

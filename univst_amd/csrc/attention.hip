@@ -350,17 +350,33 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // delta and O^T is rescaled after the pending PV, the order T13 requires.
 // TAG only names the symbol: 0 = self-attention, 1 = the 77-key text cross-attention of the same level (same code; separate rows
 // in rocprofv3 --stats, so a per-symbol average means one kind of launch)
-template <bool FOLD, int TAG = 0>
+//
+// STG = 1 (round 3): the K/V ring is filled by LDS-DMA (global_load_lds, 16 B per lane) instead of global -> registers -> ds_write.
+// An ablation of the register-staged kernel (loads + stores removed, stale tiles) ran 21 % faster: per tile and wave 4 asm loads,
+// an exposed vmcnt(0), 4 ds_write_b128 (13 cycles each, 24 % bank-conflicted) and their address arithmetic sat in a VALU-issue-bound
+// loop.  The DMA writes lane-linear 16-byte pieces, so a stage is stored CHUNK-MAJOR: plane c = the 16-byte chunk c (8 head-dim
+// columns) of all 64 key rows, 1 KB, filled by ONE wave instruction whose lane = key row.  K: 8 planes of 1024 B (0..4 data, 5 = the
+// folded-reference constants (1, 1, 1, 0..), 6 / 7 zero — written once); the QK^T fragment of lane (key l15, g) is chunk ks*4+g of
+// its row: plane stride 1024 B == 0 mod the 256-B bank span, so the rows of a ds_read_b128 lane group fall into disjoint banks.
+// V: 6 planes (5 = the ones column) 1152 B apart — the two planes a ds_read_b64_tr_b16 group touches differ by 128 B mod 256 B.
+// Ten DMA instructions per tile and BLOCK (2.5 per wave), no staging registers, and the only wait is the vmcnt(0) hipcc puts in
+// front of the tile's barrier, a whole tile after the issue.  Rows past Nkv read a device zero page.
+__device__ __attribute__((aligned(256))) half_t uv_attn_zero_page[128];
+
+template <bool FOLD, int TAG = 0, int STG = 0>
 __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
+    constexpr int NW = 4;
     constexpr int D = 40, DV16 = 3, QB = 4, NST = 3;
     constexpr int KSTR = lds_stride_bytes(64 * 2) / 2;       // 80 halfs
     constexpr int VSTR = lds_stride_bytes(48 * 2) / 2;       // 48 halfs
-    constexpr int TILE = KT * KSTR + KT * VSTR;              // 16 KB per stage
+    constexpr int KPL = 512, VPL = 576;                      // STG: plane strides in halfs (1024 B / 1152 B)
+    constexpr int KAREA = STG ? 8 * KPL : KT * KSTR;         // halfs of a stage taken by K
+    constexpr int TILE = STG ? 8 * KPL + 6 * VPL : KT * KSTR + KT * VSTR;              // 14.75 KB / 16 KB per stage
     __shared__ __attribute__((aligned(16))) half_t smem[NST * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
+    const int nqb = (p.Nq + 64 * NW - 1) / (64 * NW);
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     // Head-major order: consecutive logical blocks (= one XCD after xcd_remap) are the query blocks of ONE head over consecutive
     // frames.  Frame f+1 shares two of its three key sources with frame f (the clip's first frame and f itself), so their K/V
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     h8 qf[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
+        const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int dc = ks * 32 + g * 8;
@@ -414,7 +430,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     }
 
     // ---- staging (see attn_body): 5 chunks of 16 B per K / V row, asm loads, explicit wait at store time
-    constexpr int DCH = D / 8, NL = 2, REM = KT * DCH - 256;
+    constexpr int DCH = D / 8, NL = STG ? 1 : 2, REM = KT * DCH - 256;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     h8 kr[NL], vr[NL];
     unsigned gcol[NL], ksoff[NL], vsoff[NL];
@@ -437,6 +453,12 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     long ld_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc]) * p.Nkv * p.ldkv;
     bool ld_tail = false;
     int ld_t0 = 0;
+    auto advance_ld = [&]() {
+        if (++ld_t == ntile) {
+            ld_t = 0;
+            if (++ld_s < nsrc_eff) ld_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc + ld_s]) * p.Nkv * p.ldkv;
+        }
+    };
     auto load_tile = [&]() {
         const int t0 = ld_t * KT;
         const half_t* kb = p.k + ld_off + (long)t0 * p.ldkv;
@@ -453,10 +475,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
                 vr[i] = gload16(vb + off);
             }
         }
-        if (++ld_t == ntile) {
-            ld_t = 0;
-            if (++ld_s < nsrc_eff) ld_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc + ld_s]) * p.Nkv * p.ldkv;
-        }
+        advance_ld();
     };
     auto store_tile = [&](half_t* buf) {
         asm volatile("s_waitcnt vmcnt(0)");
@@ -470,38 +489,78 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
             }
         }
     };
+    // STG: plane j of the tile (0..4 = K chunks, 5..9 = V chunks) is one DMA instruction of wave j % 4; lane = key row.
+    // Inline asm on purpose (as the register prefetch above): for the builtin, hipcc's waitcnt pass assumes that the
+    // ds_read_b64_tr_b16 intrinsic may alias the LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of the first V fragment
+    // read of every tile, i.e. waits for the tile it has just requested.  M0 (the DMA's LDS base) is saved and restored inside
+    // the statement; the single wait is the explicit vmcnt(0) in front of the tile's barrier.
+    const half_t* const zpage = uv_attn_zero_page;
+    const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) half_t*)smem);      // LDS byte address of the ring
+    auto glds16 = [](const half_t* src, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+    };
+    auto dma_tile = [&](int stage_half) {                        // stage_half: offset of the stage in halfs from smem
+        const int t0 = ld_t * KT;
+        const bool rok = t0 + lane < p.Nkv;
+        const long roff = ld_off + (long)(t0 + lane) * p.ldkv + h * D;
+#pragma unroll
+        for (int j = 0; j < (2 * DCH + NW - 1) / NW; ++j) {
+            const int pl = wave_u + NW * j;                      // wave-uniform
+            if ((j + 1) * NW <= 2 * DCH || pl < 2 * DCH) {
+                const bool isv = pl >= DCH;
+                const int c = isv ? pl - DCH : pl;
+                const half_t* src = rok ? (isv ? p.v : p.k) + roff + c * 8 : zpage;
+                const int dst = stage_half + (isv ? KAREA + c * VPL : c * KPL);
+                glds16(src, __builtin_amdgcn_readfirstlane(smem_lds + 2u * (unsigned)dst));
+            }
+        }
+        advance_ld();
+    };
     {   // one-time LDS image: zeros, 1.0 in V column 40 (softmax denominator), FOLD: 1.0 in K columns 40..42
-        for (int i = tid * 8; i < NST * TILE; i += 256 * 8) *reinterpret_cast<h8*>(&smem[i]) = zero8;
+        for (int i = tid * 8; i < NST * TILE; i += NW * 64 * 8) *reinterpret_cast<h8*>(&smem[i]) = zero8;
         __syncthreads();
         if (tid < KT) {
 #pragma unroll
             for (int st = 0; st < NST; ++st) {
-                smem[st * TILE + KT * KSTR + tid * VSTR + D] = (half_t)1.f;
-                if (FOLD) {
-                    smem[st * TILE + tid * KSTR + D] = (half_t)1.f;
-                    smem[st * TILE + tid * KSTR + D + 1] = (half_t)1.f;
-                    smem[st * TILE + tid * KSTR + D + 2] = (half_t)1.f;
+                if (STG) {          // chunk 5 of a row = columns 40..47: plane 5 of K and of V
+                    smem[st * TILE + KAREA + 5 * VPL + tid * 8] = (half_t)1.f;
+                    if (FOLD) {
+                        smem[st * TILE + 5 * KPL + tid * 8] = (half_t)1.f;
+                        smem[st * TILE + 5 * KPL + tid * 8 + 1] = (half_t)1.f;
+                        smem[st * TILE + 5 * KPL + tid * 8 + 2] = (half_t)1.f;
+                    }
+                } else {
+                    smem[st * TILE + KT * KSTR + tid * VSTR + D] = (half_t)1.f;
+                    if (FOLD) {
+                        smem[st * TILE + tid * KSTR + D] = (half_t)1.f;
+                        smem[st * TILE + tid * KSTR + D + 1] = (half_t)1.f;
+                        smem[st * TILE + tid * KSTR + D + 2] = (half_t)1.f;
+                    }
                 }
             }
         }
+        if (STG) __syncthreads();          // the constants are in place before the first DMA is issued (no wave races ahead into a stage)
     }
 
     // ---- the four pipeline pieces
-    const int kf_off = l15 * KSTR + g * 8;
-    const int vf_off = KT * KSTR + (g * 4 + (l15 >> 2)) * VSTR + (l15 & 3) * 4;
+    const int kf_off = STG ? g * KPL + l15 * 8 : l15 * KSTR + g * 8;
+    const int vf_off = STG ? KAREA + ((l15 & 3) >> 1) * VPL + (g * 4 + (l15 >> 2)) * 8 + (l15 & 1) * 4
+                           : KT * KSTR + (g * 4 + (l15 >> 2)) * VSTR + (l15 & 3) * 4;
     auto kfrag_read = [&](const half_t* st, int hh, h8 (&kf)[2][2]) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (hh * 32 + kb * 16) * KSTR + ks * 32]);
+                kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (STG ? (hh * 32 + kb * 16) * 8 + ks * 4 * KPL : (hh * 32 + kb * 16) * KSTR + ks * 32)]);
     };
     auto vfrag_read = [&](const half_t* st, int hh, h8 (&vf)[DV16]) {
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) {
-            const half_t* vp = &st[vf_off + hh * 32 * VSTR + dv * 16];
+            const half_t* vp = &st[vf_off + (STG ? hh * 32 * 8 + dv * 2 * VPL : hh * 32 * VSTR + dv * 16)];
             fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
-            fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * VSTR));
+            fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * (STG ? 8 : VSTR)));
             h8 a;
             a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
             a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
@@ -638,11 +697,17 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 #define UV_PP_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
 
     // ---- prologue: tiles 0 and 1 into the ring, scores + reference of step (0, 0)
-    load_tile();
-    store_tile(smem);
-    if (T > 1) {
+    if (STG) {
+        dma_tile(0);
+        if (T > 1) dma_tile(TILE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
         load_tile();
-        store_tile(smem + TILE);
+        store_tile(smem);
+        if (T > 1) {
+            load_tile();
+            store_tile(smem + TILE);
+        }
     }
     __syncthreads();
 
@@ -666,7 +731,10 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 
     for (int tt = 0; tt < T; ++tt) {
         const bool has_next = tt + 1 < T;
-        if (tt + 2 < T) load_tile();                     // tile tt+2 -> registers, two tiles ahead
+        if (tt + 2 < T) {                                // tile tt+2, two tiles ahead: -> registers, or (STG) straight into the stage
+            if (STG) dma_tile((int)(b_ld - smem));       // tile tt-1 left at the last barrier; lands before this iteration's barrier
+            else load_tile();
+        }
         // ---- step (tt, 0): scores of (tt, 1) on the matrix pipe while (tt, 0) is exponentiated
         vfrag_read(b_cur, 0, vf);
         qk(kf, scB);
@@ -699,7 +767,8 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) decide(scA, mx, lw_nxt, false);
         // ---- end of tile: tile tt+2 into the stage tile tt-1 vacated one barrier ago
-        if (tt + 2 < T) store_tile(b_ld);
+        if (!STG && tt + 2 < T) store_tile(b_ld);
+        if (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile tt+2 have landed
         __syncthreads();
         half_t* tb = b_cur; b_cur = b_nxt; b_nxt = b_ld; b_ld = tb;
         t0_cur = t0_nxt;
@@ -719,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     for (int qb = 0; qb < QB; ++qb) {
         const float l = __shfl(o[DV16 - 1][qb][0], 32 + l15, 64);
         const float inv = 1.f / l;
-        const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
+        const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
 #pragma unroll
@@ -931,7 +1000,10 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         if (p.Nq >= 2048 && ((pp == 2 && p.q_prescaled) || pp == 1)) {
             const int nqb4 = (p.Nq + 255) / 256;
             const bool text = p.nsrc == 1 && p.Nkv <= 128;
+            // UNIVST_ATTN_STG (A/B aid): 1 = K/V ring filled by LDS-DMA (default), 0 = through registers
+            static const int stg = getenv("UNIVST_ATTN_STG") ? atoi(getenv("UNIVST_ATTN_STG")) : 1;
             if (pp == 2 && text) hipLaunchKernelGGL((attn_pp40_kernel<true, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else if (pp == 2 && stg) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_pp40_kernel<false, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();

@@ -28,7 +28,7 @@ def content_inversion_reconstruction(pipe, ddim_inv_scheduler, content_path, inv
                        is_opt=is_opt)[-1].to(weight_dtype)
     if reconstruct:
         print("reconstruction:")
-        sample = pipe.reconstruction("", latents=z, video_length=num_frames, guidance_scale=1.0).images
+        sample = pipe.reconstruction("", height=height, width=width, latents=z, video_length=num_frames, guidance_scale=1.0).images
         save_videos_grid(sample.permute(0, 4, 1, 2, 3).contiguous(), os.path.join(reconstruction_path, "content_video.mp4"), fps=8)
     return z
 
@@ -49,7 +49,7 @@ def style_inversion_reconstruction(pipe, ddim_inv_scheduler, style_path, inversi
                        is_opt=is_opt)[-1].to(weight_dtype)
     if reconstruct:
         print("reconstruction:")
-        sample = pipe.reconstruction("", latents=z, video_length=num_frames, guidance_scale=1.0).images
+        sample = pipe.reconstruction("", height=height, width=width, latents=z, video_length=num_frames, guidance_scale=1.0).images
         save_videos_grid(sample.permute(0, 4, 1, 2, 3).contiguous(), os.path.join(reconstruction_path, "style_video.mp4"), fps=8)
     return z
 
