@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo stages through the host, bring-up only)")
+    ap.add_argument("--comm", default=None, choices=["ipc", "dist"],
+                    help="frame-shard communicator for --gpus > 1: ipc = the library's own (HIP IPC peer writes + device flags, no host "
+                         "callbacks; default, falls back to dist if the mapping fails), dist = torch.distributed callbacks (RCCL / gloo)")
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
@@ -258,6 +261,8 @@ def launch_selftest(a, rank, world):
 
 def main():
     a = parse()
+    if a.comm:
+        os.environ["UNIVST_COMM"] = a.comm
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.emulate_rank:
         sys.exit(self_launch(a))
     if a.selftest_launch:
@@ -373,6 +378,7 @@ def main():
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "schedule_steps": "all 50" if a.steps == 50 else (f"{a.steps} of 50, evenly spread" if a.steps < 50 else f"{a.steps} (wrapping modulo 50)"),
                    "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
+                   "comm": None if world == 1 else type(shard.comm).__name__,
                    "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else
                                "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16")},
     }

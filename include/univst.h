@@ -84,6 +84,29 @@ typedef int (*univst_kv_exchange_fn)(void* user, int64_t off_send_last, int64_t 
 int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int64_t comm_ws_bytes,
                          univst_allreduce_fn ar, univst_kv_exchange_fn kv, void* user);
 
+/* The library's own frame-shard communicator (csrc/comm.hip): one process per GPU of ONE node, peers' regions mapped
+ * through HIP IPC, all three couplings (GroupNorm statistics all-reduce, K/V halo + first-frame broadcast, latent_adain statistics)
+ * as device-side peer writes + flags on the caller's stream — no host callbacks, so a forward() is a pure stream of kernels.
+ * Replaces what the reference would need for `attention.py:384-413` / the 5-D GroupNorms of `resnet.py:338,369` across GPUs (the
+ * reference itself is single-GPU).  Bring-up sequence on every rank:
+ *   univst_comm_create(rank, world, ws_bytes, &c)      ws_bytes >= 64 KiB + 6 x the largest K/V frame pack (B*N*2C fp16)
+ *   univst_comm_export(c, handle)                      univst_comm_handle_bytes() bytes, to be all-gathered out of band
+ *   univst_comm_connect(c, all_handles)                rank-major array of every rank's handle
+ *   univst_unet_set_comm_native(unet, c)               the UNet graph now uses it instead of callbacks
+ * Every wait is bounded; a rank that gives up records a code (univst_comm_status) and the next call returns UNIVST_ERR_STATE. */
+typedef struct univst_comm univst_comm;
+int univst_comm_create(int rank, int world, int64_t ws_bytes, univst_comm** out);
+int univst_comm_handle_bytes(void);
+int univst_comm_export(univst_comm* c, void* handle_out);
+int univst_comm_connect(univst_comm* c, const void* handles);
+/* ranks that are host threads of ONE process (tests on a 1-GPU box): `all` = the `world` communicators in rank order */
+int univst_comm_connect_local(univst_comm* c, univst_comm* const* all);
+int univst_comm_destroy(univst_comm* c);
+/* in-place SUM over ranks of n <= 1024 fp32 in device memory, identical bits on every rank (slots summed in rank order) */
+int univst_comm_allreduce_f32(univst_comm* c, void* buf, int n, void* stream);
+int univst_comm_status(univst_comm* c);
+int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
+
 /* tuning switches of a handle (not part of the reference's surface; tests use them for A/B runs).
  *   "ln_fold" (default 1, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
  *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU). */

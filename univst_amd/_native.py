@@ -42,6 +42,15 @@ SIGNATURES = {
     "univst_unet_forward": (_I, [_P, _P, _F, _P, _I, _I, _I, _I, _I, C.POINTER(PnP), _P, _P, _I, _P]),
     "univst_unet_set_comm": (_I, [_P, _I, _I, _P, _L, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
     "univst_unet_set_option": (_I, [_P, C.c_char_p, _I]),
+    "univst_comm_create": (_I, [_I, _I, _L, C.POINTER(_P)]),
+    "univst_comm_handle_bytes": (_I, []),
+    "univst_comm_export": (_I, [_P, _P]),
+    "univst_comm_connect": (_I, [_P, _P]),
+    "univst_comm_connect_local": (_I, [_P, C.POINTER(_P)]),
+    "univst_comm_destroy": (_I, [_P]),
+    "univst_comm_allreduce_f32": (_I, [_P, _P, _I, _P]),
+    "univst_comm_status": (_I, [_P]),
+    "univst_unet_set_comm_native": (_I, [_P, _P]),
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "univst_linear_ln": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),

@@ -94,6 +94,11 @@ int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int
     return UV_OK;
 }
 
+int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm) {
+    UV_REQUIRE(h && comm, "set_comm_native: null argument");
+    return uv_unet_attach_comm(h->impl, comm);
+}
+
 int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                   int M, int N, int K, int geglu, void* s) {
     UV_REQUIRE(X && W && Y, "linear: null argument");

@@ -8,6 +8,13 @@
 #include "common.h"
 
 typedef univst_pnp univst_pnp_t;
+struct UNet;
+// comm.hip
+int uv_unet_attach_comm(UNet& u, univst_comm* c);
+void uv_comm_bind_stream(univst_comm* c, hipStream_t s);
+unsigned uv_comm_kv_parity(const univst_comm* c);
+int uv_comm_poll(univst_comm* c);
+int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s);
 
 struct WTensor {
     half_t* ptr = nullptr;
@@ -51,6 +58,7 @@ struct UNet {
     void* comm_user = nullptr;
     char* comm_ws = nullptr;
     long comm_ws_bytes = 0;
+    struct univst_comm* native_comm = nullptr;   // set when the hooks above are the library's own IPC communicator (comm.hip)
 
     ~UNet();
     int load_tensor(const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, hipStream_t s);

@@ -572,9 +572,13 @@ struct Fwd {
     // rank's first frame lives on rank-1 and frame 0 on rank 0.  Packs are [B, N, 2C] (K|V of one frame per branch).
     int kv_exchange(half_t* qkv, int C, int N) {
         const long nbytes = (long)B * N * 2 * C * sizeof(half_t);
-        const long slot = ((u.comm_ws_bytes - 65536) / 4) & ~255L;
+        // host-callback communicator: 4 slots [send | first | recv prev | recv first].  Native (IPC) communicator: the two receive slots
+        // are double-buffered by exchange parity (peers write them without an acknowledgement, comm.hip): 6 slots
+        const int nslot = u.native_comm ? 6 : 4;
+        const long slot = ((u.comm_ws_bytes - 65536) / nslot) & ~255L;
         UV_REQUIRE(nbytes <= slot, "kv_exchange: comm workspace too small (%ld B per slot, need %ld)", slot, nbytes);
-        const long o_send = 65536, o_first = o_send + slot, o_prev = o_first + slot, o_rfirst = o_prev + slot;
+        const long par = u.native_comm ? uv_comm_kv_parity(u.native_comm) : 0;
+        const long o_send = 65536, o_first = o_send + slot, o_prev = o_first + slot * (1 + 2 * par), o_rfirst = o_prev + slot;
         if (u.rank < u.world - 1) RUN(uv_launch_kv_pack(qkv, 3 * C, C, N, B, F, F - 1, (half_t*)(u.comm_ws + o_send), s));
         if (u.rank == 0) RUN(uv_launch_kv_pack(qkv, 3 * C, C, N, B, F, 0, (half_t*)(u.comm_ws + o_first), s));
         int rc = u.kv_exchange(u.comm_user, o_send, o_first, o_prev, o_rfirst, nbytes);
@@ -742,6 +746,10 @@ int UNet::missing_error() {
 int UNet::forward(const half_t* sample, float timestep, const half_t* text, int B, int F, int H, int Wd, int text_len,
                   const univst_pnp_t* pnp, half_t* eps_out, half_t* feat_out, int ft_index, hipStream_t s) {
     UV_REQUIRE(finalized, "forward: call univst_unet_finalize after loading weights");
+    if (native_comm) {
+        RUN(uv_comm_poll(native_comm));          // a peer timed out in an earlier call: report instead of queueing more work
+        uv_comm_bind_stream(native_comm, s);
+    }
     UV_REQUIRE(B >= 1 && B <= 8 && F >= 1 && H >= 8 && Wd >= 8 && H % 8 == 0 && Wd % 8 == 0,
                "forward: unsupported geometry B=%d F=%d H=%d W=%d (H, W multiples of 8; B <= 8)", B, F, H, Wd);
     RUN(reserve(B, F, H, Wd));

@@ -12,12 +12,19 @@ branch) and every per-frame op stay local.  Three couplings cross ranks (SURVEY.
      xGMI ring).
   3. latent_adain (1 + 5 calls per run): content statistics over (F,h,w) -> all-reduce of [C, 2] fp32.
 
-The native library never links RCCL: it calls back into this module on the host while it enqueues the UNet, and the
-callbacks enqueue the collective on the same stream (torch.distributed orders its communicator stream against the
-current stream with events).  ``Comm`` is the only object that touches ``torch.distributed``; tests swap it for
-``ThreadLoopbackComm`` (ranks = host threads sharing one GPU) to validate the exchange schedule on a 1-GPU box, and
-for a gloo-backed CPU instance to validate the sharded algorithm against the unsharded oracle.
+Two interchangeable communicators sit behind the UNet graph's two hooks:
+
+  * ``NativeIpcComm`` (default on one node): the library's own communicator (csrc/comm.hip, ``univst_comm_*``) — peers' regions
+    mapped through HIP IPC, every coupling a device-side peer write + flag on the UNet's stream.  No host callback runs during a
+    forward; ``torch.distributed`` is used once, to all-gather the IPC handles (and for the final frame all-gather).
+  * ``TorchDistComm`` / ``HostStagedDistComm``: host callbacks that enqueue RCCL / gloo collectives through ``torch.distributed``
+    (the round-1/2 path; kept as the fallback when IPC mapping fails, e.g. across nodes, and for CPU-side tests).
+
+Tests swap in ``ThreadLoopbackComm`` (ranks = host threads sharing one GPU) to validate the exchange schedule on a 1-GPU box, a
+gloo-backed CPU instance to validate the sharded algorithm against the unsharded oracle, and two PROCESSES sharing the GPU for both
+communicators.
 """
+import os
 import ctypes as C
 import threading
 from typing import List, Optional
@@ -58,10 +65,19 @@ class FrameShard:
         a rebuilt native handle (``.half()``, ``load_state_dict`` ...) is re-registered the same way."""
         if self.world == 1:
             return
+        self._branches, self._max_channels = branches, max_channels
         if self.comm is None:
             import torch.distributed as dist
-            self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
-        self._branches, self._max_channels = branches, max_channels
+            kind = os.environ.get("UNIVST_COMM", "ipc")
+            if kind == "ipc":
+                try:
+                    self.comm = NativeIpcComm(self.rank, self.world, self._ws_bytes(unet, max_tokens), device=unet.device)
+                except Exception as e:       # every rank fails or none does (the self-test is a collective): fall back together
+                    if self.rank == 0:
+                        print(f"[univst_amd] native IPC communicator unavailable ({type(e).__name__}: {e}); using torch.distributed callbacks", flush=True)
+                    self.comm = None
+            if self.comm is None:
+                self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
         self._tokens, self._handle = 0, None
         self.error = None
         unet._frame_shard = self
@@ -77,10 +93,12 @@ class FrameShard:
         if handle is self._handle and tokens <= self._tokens:
             return
         tokens = max(tokens, self._tokens)
-        boc = unet.config.block_out_channels
-        # largest K|V pack: B * N * 2C fp16 over the attention levels (N shrinks 4x per level while C grows <= 2x)
-        pack = max(self._branches * (tokens >> (2 * i)) * 2 * c * 2 for i, c in enumerate(boc[:3]))
-        nbytes = 65536 + 4 * ((pack + 255) // 256 * 256) + 4096
+        if isinstance(self.comm, NativeIpcComm):     # the communicator owns the (IPC-shared) workspace; no callbacks
+            self.comm.ensure_bytes(self._ws_bytes(unet, tokens))
+            _native.check(_native.load().univst_unet_set_comm_native(handle, self.comm.ptr), "unet_set_comm_native")
+            self._tokens, self._handle = tokens, handle
+            return
+        nbytes = self._ws_bytes(unet, tokens, slots=4)
         if self.ws is None or self.ws.numel() < nbytes:
             self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=unet.device)
         nbytes = self.ws.numel()
@@ -109,6 +127,13 @@ class FrameShard:
         _native.check(_native.load().univst_unet_set_comm(handle, self.rank, self.world, self.ws.data_ptr(), nbytes, ar, kv, None),
                       "unet_set_comm")
         self._tokens, self._handle = tokens, handle
+
+    def _ws_bytes(self, unet, tokens: int, slots: int = 6) -> int:
+        """64 KiB (GroupNorm partials) + `slots` K|V packs of a `tokens`-token latent: the largest pack is B * N * 2C fp16 over the
+        attention levels (N shrinks 4x per level while C grows <= 2x)."""
+        boc = unet.config.block_out_channels
+        pack = max(self._branches * (tokens >> (2 * i)) * 2 * c * 2 for i, c in enumerate(boc[:3]))
+        return 65536 + slots * ((pack + 255) // 256 * 256) + 4096
 
     def raise_pending(self, what: str):
         """a collective failed inside a native call: surface the original exception on THIS rank right away (the process
@@ -156,6 +181,80 @@ class FrameShard:
 
 
 # ------------------------------------------------------------------------------------------------ communicators
+class NativeIpcComm:
+    """The library's own communicator (include/univst.h ``univst_comm_*``, csrc/comm.hip): device-side peer writes + flags through
+    IPC-mapped fine-grained memory.  ``torch.distributed`` (any backend) only carries the 64-byte handles at bring-up and the final
+    frame all-gather; ``exchange`` may replace it (callable: bytes -> list of every rank's bytes)."""
+
+    def __init__(self, rank: int, world: int, ws_bytes: int, device=None, exchange=None):
+        self.rank, self.world = rank, world
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._exchange = exchange or self._dist_exchange
+        self.ptr, self.ws_bytes = None, 0
+        self._build(ws_bytes)
+
+    @staticmethod
+    def _dist_exchange(blob: bytes):
+        import torch.distributed as dist
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, blob)
+        return out
+
+    def _build(self, ws_bytes: int):
+        lib = _native.load()
+        if self.ptr is not None:
+            torch.cuda.synchronize()
+            lib.univst_comm_destroy(self.ptr)
+            self.ptr = None
+        h = C.c_void_p()
+        _native.check(lib.univst_comm_create(self.rank, self.world, int(ws_bytes), C.byref(h)), "comm_create")
+        self.ptr, self.ws_bytes = h, int(ws_bytes)
+        nb = lib.univst_comm_handle_bytes()
+        mine = C.create_string_buffer(nb)
+        _native.check(lib.univst_comm_export(h, mine), "comm_export")
+        blobs = self._exchange(mine.raw)
+        if len(blobs) != self.world or any(len(b) != nb for b in blobs):
+            raise RuntimeError("IPC handle exchange returned a malformed list")
+        _native.check(lib.univst_comm_connect(h, b"".join(blobs)), "comm_connect")
+        # self-test (a collective): sum of (rank + 1) * (i + 1) must come out exactly, on every rank
+        t = torch.arange(1, 65, device=self.device, dtype=torch.float32) * (self.rank + 1)
+        self.all_reduce_sum(t)
+        torch.cuda.synchronize()
+        want = torch.arange(1, 65, dtype=torch.float32) * (self.world * (self.world + 1) // 2)
+        if lib.univst_comm_status(h) or not torch.equal(t.cpu(), want):
+            raise RuntimeError(f"IPC all-reduce self-test failed on rank {self.rank} (status {lib.univst_comm_status(h)})")
+
+    def ensure_bytes(self, ws_bytes: int):
+        """grow the shared workspace (a collective: every rank sees the same latent sizes, hence the same growth sequence)."""
+        if ws_bytes > self.ws_bytes:
+            self._build(ws_bytes)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _native.check(_native.load().univst_comm_allreduce_f32(self.ptr, t.data_ptr(), t.numel(), _native.stream_ptr()), "comm_allreduce")
+
+    def all_gather(self, t: torch.Tensor) -> List[torch.Tensor]:
+        import torch.distributed as dist
+        if dist.get_backend() == "nccl":
+            outs = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(outs, t)
+            return outs
+        c = t.detach().to("cpu")
+        outs = [torch.empty_like(c) for _ in range(self.world)]
+        dist.all_gather(outs, c)
+        return [o.to(t.device) for o in outs]
+
+    def abort(self):
+        pass
+
+    def __del__(self):
+        try:
+            if self.ptr is not None:
+                _native.load().univst_comm_destroy(self.ptr)
+        except Exception:
+            pass
+
+
 class TorchDistComm:
     """RCCL (or gloo on CPU) through torch.distributed; all ops are enqueued against the current stream."""
 
