@@ -257,3 +257,122 @@ def test_mask_propagation_bit_exact_full_size():
                                  foreground_px_last=int((ref[-1] != 0).sum())))
     assert got.shape == ref.shape == (16, 512, 512) and got.dtype == np.uint8
     assert sum(diff) == 0, diff
+
+
+def test_warp_and_sliding_window_bit_exact_16x512x512():
+    """SURVEY §8 a16 at the BASELINE size: the fused occlusion + fixed-point remap + composite kernel and the whole Gauss-Seidel
+    sliding window (stable_diffusion.py:723-751, cal_optica_flow.py:20-46: 58 warps, 116 flows) on 16 frames of 512x512, BIT-EXACT
+    against oracle/flow_ref (numpy; its remap is pinned by the hand-computed OpenCV vectors of tests/golden/remap_opencv_cases.json).
+    The call-counted flows cover sub-pixel offsets on and off the 1/32 grid, flows that leave the image on every border, and
+    patches that trip the 1.5 px forward-backward test; a 30 % keep-mask is restored at the end."""
+    from oracle import flow_ref
+    from univst_amd.src import cal_optica_flow as cf
+    H = W = 512
+    F_ = 16
+    rs = np.random.RandomState(11)
+    frames = rs.randint(0, 256, (1, 3, F_, H, W)).astype(np.uint8)
+    frames[0, :, 3, 100:200, 50:300] = 255          # saturated and flat regions: rounding at 255 / exact reproduction
+    frames[0, :, 7, 300:400, :] = 0
+    mask = (rs.rand(F_, H, W) > 0.7).astype(np.uint8)
+
+    class Flows:
+        def __init__(self):
+            self.k = 0
+
+        def __call__(self, a=None, b=None):
+            k = self.k
+            self.k += 1
+            sg = 1.0 if k % 2 == 0 else -1.0
+            f = si.translation_flow(H, W, sg * (0.03125 * (k % 64) + (k % 5)), -sg * (0.015625 * (k % 32) + (k % 3)), 900 + k, noise=0.3)
+            if k % 3 == 0:
+                f[:, :12, 0] -= 20.0                 # left border: samples from outside the image
+                f[-9:, :, 1] += 17.0                 # bottom border
+            if k % 2 == 1:
+                f[H // 8:H // 4, W // 4:W // 2] += 3.0      # occluded patch (forward + backward no longer cancel)
+            return f.astype(np.float32)
+    fo, fn = Flows(), Flows()
+    t0 = time.time()
+    ref = flow_ref.sliding_window_smooth(frames, fo, mask[None])
+    t_oracle = time.time() - t0
+    torch.cuda.synchronize()
+    t0 = time.time()
+    got = cf.sliding_window_smooth(torch.from_numpy(frames).cuda(), lambda a, b: torch.from_numpy(fn()).cuda(), torch.from_numpy(mask).cuda())
+    torch.cuda.synchronize()
+    t_native = time.time() - t0
+    got = got.cpu().numpy()
+    assert fo.k == fn.k == 2 * 58
+    ndiff = int((got != ref).sum())
+    record("sliding_window_16x512x512", dict(differing_values=ndiff, of=int(ref.size), native_s=t_native, oracle_numpy_s=t_oracle,
+                                             changed_by_smoothing=int((ref != frames).sum())))
+    assert ndiff == 0, f"{ndiff} of {ref.size} smoothed values differ"
+    assert (ref != frames).mean() > 0.3, "the window must actually change the unmasked pixels"
+
+
+def test_f16_pixel_smoother_leg_vs_oracle_on_device(sd15):
+    """BASELINE config 3's smoothing leg at the BASELINE size (stable_diffusion.py:713-759, 782-834): SD-v1.5 widths, F = 16, 64x64
+    latents = 16 x 512 x 512 frames, steps 0..25 of the localized transfer with the pixel smoother active on steps 20..24 —
+    pred_original_sample, VAE decode to uint8, HIP sliding window (58 warps per step) with the masked restore, VAE encode,
+    return_to_timestep — native pipeline vs the oracle loop (UNet oracle in fp32 on the device, flow_ref smoothing in numpy), with
+    the deterministic linear fake VAE and call-counted analytic flows in place of the third-party VAE / RAFT.
+    PSNR >= 40 dB on the latents after steps 19..25; the un-smoothed run must be clearly further away (the leg is reproduced)."""
+    from univst_amd.backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
+    from univst_amd.backbones.video_diffusion_sd import pnp_utils
+    from univst_amd.schedulers import DDIMScheduler
+    unet, sd = sd15
+    cfg = unet_ref.SD15_CONFIG
+    F_, h, w, n = 16, 64, 64, 50
+    text = si.text_embedding(768)
+    vae = si.FakeLinearVAE().cuda()
+    pipe = SpatioTemporalStableDiffusionPipeline(vae=vae, text_encoder=_enc(text), tokenizer=_Tok(), unet=unet, scheduler=DDIMScheduler())
+    ci = [si.content_latent(k, F_, h, w).half() for k in range(n + 1)]
+    sy = [si.style_latent(k, F_, h, w).half() for k in range(n + 1)]
+    masks = torch.from_numpy(pipeline_ref.mask_from_png_values(si.disc_masks(F_, 512, 512)))[None]
+    lat0 = pnp_utils.latent_adain(ci[n].cuda(), sy[n].cuda())
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    keep = (19, 20, 21, 22, 23, 24, 25)
+
+    class Stop(Exception):
+        pass
+
+    def collect(store):
+        def cb(i, t, l):
+            if i in keep:
+                store[i] = l.clone()
+            if i == keep[-1]:
+                raise Stop()
+        return cb
+    gflow = si.CountingFlow(512, 512)
+    got, plain = {}, {}
+    t0 = time.time()
+    with pytest.raises(Stop):
+        pipe.video_style_transfer("", latents=lat0, num_inference_steps=n, content_inv_latents=ci, style_inv_latents=sy, masks=masks,
+                                  output_type="latent", smoother="pixel", flow_fn=lambda a, b: torch.from_numpy(gflow()).cuda(),
+                                  callback=collect(got))
+    torch.cuda.synchronize()
+    t_native = time.time() - t0
+    assert gflow.k == 5 * 2 * 58
+    with pytest.raises(Stop):
+        pipe.video_style_transfer("", latents=lat0, num_inference_steps=n, content_inv_latents=ci, style_inv_latents=sy, masks=masks,
+                                  output_type="latent", callback=collect(plain))
+    ctx = text.half().float().cuda().expand(3, -1, -1).contiguous()
+    cif = [t.float().cuda() for t in ci]
+    syf = [t.float().cuda() for t in sy]
+    osch = pipeline_ref.DDIMSchedule()
+    osch.set_timesteps(n)
+    oflow = si.CountingFlow(512, 512)
+    ref = {}
+    t0 = time.time()
+    with torch.no_grad(), pytest.raises(Stop):
+        pipeline_ref.video_style_transfer_loop(
+            lambda x, t, i: unet_ref.unet_forward(sd, cfg, x, int(t), ctx, pnp_idx=i, exact_temporal=False)[0],
+            osch, unet_ref.latent_adain(cif[n], syf[n]), cif, syf, masks.cuda(), n,
+            smoother=pipeline_ref.pixel_smoother(osch, vae.decode_tensor, lambda x: vae.encode_tensor(x.cuda()), oflow, masks.numpy()),
+            callback=collect(ref))
+    torch.cuda.synchronize()
+    t_oracle = time.time() - t0
+    vals = {f"i{i}": psnr(got[i], ref[i]) for i in keep}
+    off = {f"i{i}": psnr(plain[i], ref[i]) for i in keep}
+    record("pixel_smoother_leg_f16", dict(psnr_db=vals, unsmoothed_psnr_db=off, native_s=t_native, oracle_s=t_oracle))
+    assert torch.equal(plain[19], got[19]) and not torch.equal(plain[20], got[20])
+    assert all(v >= 40.0 for v in vals.values()), vals
+    assert all(vals[f"i{i}"] >= off[f"i{i}"] + 6.0 for i in (20, 21, 22, 23, 24)), (vals, off)

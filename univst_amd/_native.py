@@ -229,12 +229,15 @@ def attention(q, k, v, src_idx, heads, ldq=None, ldkv=None, Nq=None, Nkv=None, C
     return out
 
 
-def attention_adain_shift_(qkv, F, N, C_, alpha, beta, gamma):
-    """in place on the fused [3*F*N, 3C] buffer."""
+def attention_adain_shift_(qkv, F, N, C_, alpha, beta, gamma, return_stats=False):
+    """in place on the fused [3*F*N, 3C] buffer.  return_stats: also the style branch's per-(frame, channel) statistics the kernel
+    used, (mean, unbiased std) each [F, 2C] (K columns then V columns)."""
     _f16(qkv)
     ws = torch.empty(4 * F * 2 * C_, device=qkv.device, dtype=torch.float32)
     check(load().univst_attention_adain_shift(ptr(qkv), qkv.shape[-1], F, N, C_, alpha, beta, gamma, ptr(ws), stream_ptr()),
           "attention_adain_shift")
+    if return_stats:
+        return qkv, ws[:F * 2 * C_].view(F, 2 * C_), ws[F * 2 * C_:2 * F * 2 * C_].view(F, 2 * C_)
     return qkv
 
 

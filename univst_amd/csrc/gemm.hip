@@ -992,15 +992,29 @@ static bool uv_conv_patch_eligible(const GemmParams& p, int bmb) {
            bmb % p.Wo == 0 && (bmb / p.Wo + 2 + bmb / p.Wo / p.Ho + 1) * (p.Wo + 2) <= 512 && !p.geglu;
 }
 
-// Does a plain linear of this shape take the direct (no split-K) 256x320 path whose epilogue can fold a LayerNorm / emit row
-// statistics?  Mirrors the dispatch in uv_launch_gemm (which re-checks and fails loudly on a mismatch).
-bool uv_linear_takes_big_direct(long M, int N, int K) {
-    static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
-    static const long bigmin_env = getenv("UNIVST_GEMM_BIGMIN") ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 0;
-    const long bigmin = bigmin_env ? bigmin_env : 150;
-    if (nobig || N % 320 != 0 || (long)N * K >= (1L << 31) || M * (long)K >= (1L << 31)) return false;
+// ONE copy of what the 256x320 path requires of a problem's shape / environment: used by the launcher below and by the predicate the
+// UNet graph consults before it decides to fold a LayerNorm (the two used to be separate copies that could drift apart).
+struct BigEnv {
+    int nobig, epi;
+    long bigmin;
+};
+static const BigEnv& big_env() {
+    static const BigEnv e = {getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0,
+                             getenv("UNIVST_GEMM_EPI") ? atoi(getenv("UNIVST_GEMM_EPI")) : 1,
+                             (getenv("UNIVST_GEMM_BIGMIN") && atol(getenv("UNIVST_GEMM_BIGMIN"))) ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 150};   // measured cross-over (tools/bench_gemm_mid.py)
+    return e;
+}
+static bool big_shape_ok(int N, int K, long x_elems) {      // x_elems: extent of the activation operand in elements (32-bit DMA offsets)
+    return !big_env().nobig && N % 320 == 0 && (long)N * K < (1L << 31) && x_elems < (1L << 31);
+}
+
+// Does a plain linear [M, K] (row stride ldx, 0 = K) x [N, K]^T take the direct (no split-K) 256x320 path whose epilogue can fold a
+// LayerNorm / emit row statistics?  Same conditions as the launcher (which still re-checks and fails loudly on a mismatch), incl.
+// the LDS epilogue switch; pointer alignment is the caller's business (the UNet arena is 256-byte aligned).
+bool uv_linear_takes_big_direct(long M, int N, int K, long ldx) {
+    if (!big_shape_ok(N, K, M * (ldx ? ldx : (long)K)) || big_env().epi == 0) return false;
     const long n256 = ((M + 255) / 256) * (N / 320), n192 = ((M + 191) / 192) * (N / 320);
-    return n256 >= bigmin && n192 >= bigmin;      // whichever tile height the launcher picks
+    return n256 >= big_env().bigmin && n192 >= big_env().bigmin;      // whichever tile height the launcher picks
 }
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
@@ -1016,7 +1030,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         UV_REQUIRE(!p.korder || (p.taps == 9 && p.C1 % 64 == 0 && p.C2 % 64 == 0), "conv: tap-inner k order needs taps=9 and 64-channel slabs");
     }
     {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
-        static const int nobig = getenv("UNIVST_GEMM_NOBIG") ? atoi(getenv("UNIVST_GEMM_NOBIG")) : 0;
+        const int nobig = big_env().nobig;
         // tile height: 256 rows, or 192 when that fills whole rounds of the CUs better (49152 x 640 is 384 tiles of 256 = 1.5
         // rounds but 512 tiles of 192 = 2 exact ones; 12288 x 1280 is 192 vs 256 tiles)
         static const int bm_env = getenv("UNIVST_GEMM_BM") ? atoi(getenv("UNIVST_GEMM_BM")) : 0;     // A/B aid: force 256 / 192
@@ -1027,8 +1041,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         const bool use192 = bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150);
         const long nblk = use192 ? n192 : n256;
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
-        static const long bigmin_env = getenv("UNIVST_GEMM_BIGMIN") ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 0;
-        const long bigmin = bigmin_env ? bigmin_env : 150;   // measured cross-over (tools/bench_gemm_mid.py)
+        const long bigmin = big_env().bigmin;
         // few tiles but a long reduction (the 8x8-level convs; most convs of a frame shard): the big tile with split-K
         int bsplits = 1;
         static const int splitk_big = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
@@ -1042,12 +1055,12 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         const bool use_patch = patch_env && mode == 1 && (nblk >= bigmin || bsplits > 1) && uv_conv_patch_eligible(p, use192 ? 192 : 256);
         UV_REQUIRE(p.W || use_patch, "conv: only the [Cin/32][9][32] weight copy was given but the problem is not eligible for the LDS-patch kernel "
                    "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles or a reduction long enough for split-K)");
-        if (!nobig && p.N % 320 == 0 && (nblk >= bigmin || bsplits > 1) && (long)p.N * p.K < (1L << 31) && xmax < (1L << 31)) {
+        if (big_shape_ok(p.N, p.K, xmax) && (nblk >= bigmin || bsplits > 1)) {
             uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K,
                           2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
             // row-contiguous epilogue through LDS needs 16-byte aligned rows everywhere it touches; it pays for the plain
             // and residual epilogues (-12..19 % at K=320) but not for GEGLU, whose stores are half as many (UNIVST_GEMM_EPI=2 forces it)
-            static const int epi = getenv("UNIVST_GEMM_EPI") ? atoi(getenv("UNIVST_GEMM_EPI")) : 1;
+            const int epi = big_env().epi;
             auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
             GemmParams q = p;
             {   // row-group x column-block tile order for wide outputs (see gemm_big_kernel); UNIVST_GEMM_TILEORDER=0: column-fastest

@@ -63,7 +63,7 @@ struct AttnParams {
 };
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
-bool uv_linear_takes_big_direct(long M, int N, int K);
+bool uv_linear_takes_big_direct(long M, int N, int K, long ldx = 0);
 constexpr size_t UV_SPLITK_WS_BYTES = 128u << 20;  // fp32 partials [splits][M][N]: 8 splits of the 8x8-level convs (3072 x 1280)
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);

@@ -21,6 +21,10 @@ __global__ void gn_partial_kernel(const half_t* __restrict__ s1, const half_t* _
     // Sums are taken about a per-thread, per-channel PIVOT (the first value the thread reads): sum (x-p) and sum (x-p)^2 stay
     // of the order of the spread even when |mean| >> std (real SD checkpoints have such channel groups), where a raw
     // one-pass E[x^2] - mean^2 in fp32 cancels.  The block recombines them about zero in double, in a fixed order.
+    // What this does NOT remove: the per-chunk (sum, sumsq) pair is stored — and, in a frame shard, all-reduced — as fp32, and the
+    // variance is still sumsq/n - mean^2, so ONE fp32 rounding of sumsq remains: relative variance error <= (mean/std)^2 * 2^-24
+    // (6e-6 at |mean| = 10 std, 5e-5 at 30 std, 6e-4 at 100 std; the per-thread accumulation error that grew with the row
+    // count is what the pivot removes).  Partials as (n, mean, M2) would need a second all-reduce round in the sharded case.
     extern __shared__ float sm[];                    // [TR][C] shifted sums, [TR][C] shifted sumsq, [TR][C] pivots
     const int C = C1 + C2, TC = C / 8, TR = blockDim.x / TC;
     const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;

@@ -14,21 +14,29 @@
 namespace {
 
 // per-(frame, column) mean and unbiased std over N rows.  block = 8 column-chunks x 32 row phases.
+// Sums are taken about a per-thread PIVOT (the first value the thread sees) and the 32 row phases are merged Chan-style in double
+// ((n, mean, M2) triples): a raw one-pass sum(x), sum(x^2) in fp32 cancels when |mean| >> std, and style K / V columns of real
+// checkpoints are not zero-mean (same reason as the GroupNorm pivot in norm.hip; tests: test_attention_adain_shift_large_mean).
 __global__ __launch_bounds__(256) void colstats_kernel(const half_t* __restrict__ x, long ld, int N, int ncols,
                                                        float* __restrict__ mean, float* __restrict__ stdv) {
-    __shared__ float sm[2][32][64];
+    __shared__ float sm[3][32][64];
     const int tc = threadIdx.x & 7, tr = threadIdx.x >> 3;
     const int f = blockIdx.y, c0 = blockIdx.x * 64 + tc * 8;
-    float s[8], q[8];
+    float s[8], q[8], pv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
-    if (c0 < ncols) {
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = pv[e] = 0.f;
+    if (c0 < ncols && tr < N) {
         const half_t* base = x + (long)f * N * ld + c0;
-        for (int r = tr; r < N; r += 32) {
+        {
+            h8 v = *reinterpret_cast<const h8*>(base + (long)tr * ld);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = (float)v[e];
+        }
+        for (int r = tr + 32; r < N; r += 32) {
             h8 v = *reinterpret_cast<const h8*>(base + (long)r * ld);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float t = (float)v[e];
+                const float t = (float)v[e] - pv[e];
                 s[e] += t;
                 q[e] += t * t;
             }
@@ -38,18 +46,23 @@ __global__ __launch_bounds__(256) void colstats_kernel(const half_t* __restrict_
     for (int e = 0; e < 8; ++e) {
         sm[0][tr][tc * 8 + e] = s[e];
         sm[1][tr][tc * 8 + e] = q[e];
+        sm[2][tr][tc * 8 + e] = pv[e];
     }
     __syncthreads();
     if (threadIdx.x < 64) {
         const int c = blockIdx.x * 64 + threadIdx.x;
         if (c < ncols) {
-            double a = 0.0, b = 0.0;
-            for (int t = 0; t < 32; ++t) {
-                a += sm[0][t][threadIdx.x];
-                b += sm[1][t][threadIdx.x];
+            double n = 0.0, mu = 0.0, m2 = 0.0;
+            for (int t = 0; t < 32 && t < N; ++t) {
+                const double nt = (double)((N - t + 31) / 32);
+                const double st = sm[0][t][threadIdx.x], qt = sm[1][t][threadIdx.x];
+                const double mt = (double)sm[2][t][threadIdx.x] + st / nt, m2t = qt - st * st / nt;
+                const double dl = mt - mu, ntot = n + nt;
+                m2 += m2t + dl * dl * n * nt / ntot;
+                mu += dl * nt / ntot;
+                n = ntot;
             }
-            double mu = a / N;
-            double var = (b - a * mu) / (N > 1 ? (N - 1) : 1);
+            double var = m2 / (N > 1 ? (N - 1) : 1);
             if (var < 0.0) var = 0.0;
             mean[(long)f * ncols + c] = (float)mu;
             stdv[(long)f * ncols + c] = (float)sqrt(var);

@@ -40,9 +40,8 @@ def get_warp(image1_path, image2_path, ref_image1=None, ref_image2=None, occlusi
     test at 1.5 px, ``ref_image2`` warped by the forward flow and composited over ``ref_image1`` where occluded, uint8 [H,W,3].
     Images may be numpy arrays (the reference's calling convention: a numpy array comes back), uint8 device tensors (a device tensor
     comes back) or file paths.  ``flow_fn`` stands in for RAFT (third-party); when omitted the torchvision model is created ONCE per
-    process (the reference re-creates it on every call, :53-55).  The ``*_save_path`` debugging outputs need cv2 and are not supported."""
-    if occlusion_mask_save_path is not None or warped_image_save_path is not None:
-        raise NotImplementedError("occlusion_mask_save_path / warped_image_save_path need cv2.imwrite")
+    process (the reference re-creates it on every call, :53-55).  The ``*_save_path`` debugging outputs are written with PIL (the
+    reference uses cv2.imwrite; same pixels on disk: the mask as 8-bit grey, the composite as RGB)."""
     import numpy as np
 
     def dev(img):
@@ -61,8 +60,18 @@ def get_warp(image1_path, image2_path, ref_image1=None, ref_image2=None, occlusi
             _RAFT["fn"] = make_raft_flow_fn(a.device)
         flow_fn = _RAFT["fn"]
     acc = torch.zeros(*a.shape, dtype=torch.float32, device=a.device)
-    warp_accumulate_(acc, ra, rb, flow_fn(a, b), flow_fn(b, a))
+    fwd, bwd = flow_fn(a, b), flow_fn(b, a)
+    warp_accumulate_(acc, ra, rb, fwd, bwd)
     out = acc.to(torch.uint8)
+    if occlusion_mask_save_path is not None:        # cal_optica_flow.py:20-29: |fwd + bwd| > 1.5 px, pointwise
+        from PIL import Image
+        occ = ((fwd.float() + bwd.float()).norm(dim=-1) > 1.5).to(torch.uint8) * 255
+        Image.fromarray(occ.cpu().numpy(), mode="L").save(occlusion_mask_save_path)
+        print(f"Occlusion mask save at {occlusion_mask_save_path}")
+    if warped_image_save_path is not None:
+        from PIL import Image
+        Image.fromarray(out.cpu().numpy(), mode="RGB").save(warped_image_save_path)
+        print(f"Occlusion mask save at {warped_image_save_path}")      # (the reference prints this label for both files, :96)
     return out.cpu().numpy() if was_np else out
 
 
