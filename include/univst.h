@@ -163,6 +163,39 @@ int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta
 int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
                      const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv,
                      int heads, int head_dim, int q_prescaled, void* stream);
+/* ---- first vertical slice of the SD3 / SD3.5 rectified-flow path (the reference-owned pieces only) ----
+ * The joint-attention processors of backbones/video_diffusion_sd3/pnp_utils.py: CrossFrameProcessor (:17-131; shift = 0) and
+ * AttentionShiftProcessor (:143-271; shift = 1, window eta1*50 <= idx <= eta2*50, alpha 0.8 / gamma 2.0 / beta 0.9 -> 0.1, under the
+ * documented fixed reading thresh2 == eta2 — the reference reads an attribute it never sets).  hidden [B, N, Cin] image tokens of
+ * B = (branches x clip_length) frames, enc [B, Nt, Cin] text tokens or NULL; keys of frame f = image tokens of ['first', f-1, f]
+ * of its clip (read by pointer) ++ its text tokens (one extra key segment); out_img [B, N, Cin], out_txt [B, Nt, Cin].
+ * Weights are diffusers' Attention parameters, fp16 device pointers, [out, in] row-major; NULL = absent (biases, the RMS norms of
+ * SD3-medium, to_add_out when context_pre_only). */
+typedef struct {
+    const void *to_q, *to_q_bias, *to_k, *to_k_bias, *to_v, *to_v_bias;             /* [heads*head_dim, Cin] */
+    const void *norm_q, *norm_k;                                                    /* [head_dim] RMSNorm weights (SD3.5) */
+    const void *add_q, *add_q_bias, *add_k, *add_k_bias, *add_v, *add_v_bias;       /* added (text) projections */
+    const void *norm_added_q, *norm_added_k;
+    const void *to_out, *to_out_bias, *to_add_out, *to_add_out_bias;                /* [Cin, heads*head_dim] */
+} univst_sd3_attn_weights;
+int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin,
+                               int heads, int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps,
+                               void* out_img, void* out_txt, void* stream);
+/* the shift alone, in place on a fused [3*F*N, 3C] q | k | v buffer (branch 0 content, 1 style, 2 stylised; row stride ld):
+ * q2 <- gamma*(alpha*q0 + (1-alpha)*q2);  k2 <- beta*AdaIN(k2; k1) + (1-beta)*k1 (same for v) with the SD3 plugin's AdaIN
+ * (pnp_utils.py:289-302: F.instance_norm over (N, head_dim) jointly per (frame, head), style mean / unbiased std per channel over N).
+ * ws: 4*F*2C + 2*F*2*heads floats. */
+int univst_sd3_adain_shift(void* qkv, int64_t ld, int F, int N, int C, int heads, float alpha, float beta, float gamma, void* ws,
+                           void* stream);
+/* diffusers RMSNorm over the head dim, in place: x[r, h*d + e] *= rsqrt(mean_e x^2 + eps) * weight[e]  (row stride ld) */
+int univst_rmsnorm_heads(void* x, int64_t ld, int64_t rows, int heads, int head_dim, const void* weight, float eps, void* stream);
+/* y = LayerNorm(x; no affine, eps) * (1 + scale[b]) + shift[b]: AdaLayerNormZero / Continuous of the MM-DiT blocks; x, y [rows, C],
+ * scale / shift [rows / rows_per_batch, C] */
+int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t rows, int64_t rows_per_batch, int C,
+                          float eps, void* stream);
+/* out = a*x + b*y + c*z (fp16 storage, fp32 arithmetic): the updates of rf_inversion / rf_solver (flow_inversion.py:123-264) */
+int univst_axpbypcz(const void* x, const void* y, const void* z, void* out, float a, float b, float c, int64_t n, void* stream);
+
 /* AdaIN-guided attention shift in place on the fused QKV buffer [3*F*N, 3C]; stats_ws: 4*F*2C floats.
  * Replaces pnp_utils.py:47-57 + attention_adain :114-125. */
 int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, float alpha, float beta, float gamma,

@@ -137,3 +137,42 @@ def flow_match_sigmas(n: int, shift: float = 3.0, num_train_timesteps: int = 100
     s = torch.linspace(1.0, 1.0 / num_train_timesteps, n, dtype=torch.float32)
     sig = shift * s / (1 + (shift - 1) * s)
     return torch.cat([sig, torch.zeros(1)])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# THIRD-PARTY, PARITY UNPINNED: diffusers 0.35.1 `JointTransformerBlock` (models/attention.py) — the MM-DiT block that calls the
+# processors above.  diffusers is absent from the reference tree and from both boxes, so this is restated from its published
+# forward (non-dual-attention block, context_pre_only = False) and pinned by nothing but this reading; it exists so that the native
+# adaLN-modulate / RMS-norm / joint-attention operators have a block-level composition to be checked against
+# (tests/test_gpu_sd3.py), not as a claim about the SD3.5 backbone.
+def ada_layer_norm_zero(x: torch.Tensor, temb: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float = 1e-6):
+    """AdaLayerNormZero: emb = Linear(SiLU(temb)) -> (shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp);
+    returns LayerNorm(x; no affine) * (1 + scale_msa) + shift_msa and the other four."""
+    emb = F.linear(F.silu(temb), w, b)
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = emb.chunk(6, dim=1)
+    xn = F.layer_norm(x, (x.shape[-1],), None, None, eps) * (1 + scale_msa[:, None]) + shift_msa[:, None]
+    return xn, gate_msa, shift_mlp, scale_mlp, gate_mlp
+
+
+def feed_forward_gelu_tanh(x: torch.Tensor, P: Dict[str, torch.Tensor], pre: str) -> torch.Tensor:
+    """FeedForward(dim, activation_fn="gelu-approximate"): Linear(dim, 4 dim) -> GELU(tanh) -> Linear(4 dim, dim)."""
+    h = F.gelu(F.linear(x, P[pre + ".net.0.proj.weight"], P[pre + ".net.0.proj.bias"]), approximate="tanh")
+    return F.linear(h, P[pre + ".net.2.weight"], P[pre + ".net.2.bias"])
+
+
+def joint_transformer_block(P: Dict[str, torch.Tensor], heads: int, hidden: torch.Tensor, enc: torch.Tensor, temb: torch.Tensor,
+                            idx: int = -1, shift: bool = False, eta1: float = 0.0, eta2: float = 0.6, clip_length: int = 16):
+    """hidden [(b f), N, C], enc [(b f), Nt, C], temb [(b f), C] -> (enc', hidden').  P: the block's state dict
+    (norm1.linear.*, norm1_context.linear.*, attn.*, ff.*, ff_context.*)."""
+    attnP = {k[len("attn."):]: v for k, v in P.items() if k.startswith("attn.")}
+    nh, gate_msa, shift_mlp, scale_mlp, gate_mlp = ada_layer_norm_zero(hidden, temb, P["norm1.linear.weight"], P["norm1.linear.bias"])
+    ne, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = ada_layer_norm_zero(enc, temb, P["norm1_context.linear.weight"],
+                                                                              P["norm1_context.linear.bias"])
+    a_img, a_txt = joint_attention(attnP, heads, nh, ne, idx=idx, shift=shift, eta1=eta1, eta2=eta2, clip_length=clip_length)
+    hidden = hidden + gate_msa[:, None] * a_img
+    n2 = F.layer_norm(hidden, (hidden.shape[-1],), None, None, 1e-6) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
+    hidden = hidden + gate_mlp[:, None] * feed_forward_gelu_tanh(n2, P, "ff")
+    enc = enc + c_gate_msa[:, None] * a_txt
+    n2c = F.layer_norm(enc, (enc.shape[-1],), None, None, 1e-6) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
+    enc = enc + c_gate_mlp[:, None] * feed_forward_gelu_tanh(n2c, P, "ff_context")
+    return enc, hidden

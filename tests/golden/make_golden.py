@@ -572,6 +572,41 @@ def main():
         g17["rf_solver"] = dict(final=zS)
     gold["g17_sd3_rf"] = g17
 
+    # ---- G18 (round 3): the same two processors at a shape the native kernels serve (head_dim 64 as SD3 / SD3.5, 24 image + 7
+    #      text tokens: the text segment has its own length; multi-tile shapes are checked against the oracle in tests/test_gpu_sd3.py) — the target of tests/test_gpu_sd3.py.  Own generator:
+    #      nothing above changes.
+    attn18 = JointAttn(dim=128, heads=2, dim_head=64)
+    g18g = torch.Generator().manual_seed(1801)
+    for prm in attn18.parameters():
+        prm.data = torch.randn(prm.shape, generator=g18g) * (0.09 if prm.dim() > 1 else 0.1) + (1.0 if prm.dim() == 1 and prm.shape[0] == 64 else 0.0)
+    attn18.eval()
+    P18 = {kk: vv.clone() for kk, vv in attn18.state_dict().items()}
+    hid18 = torch.randn(48, 24, 128, generator=g18g)      # 3 branches x 16 frames, 24 image tokens
+    enc18 = torch.randn(48, 7, 128, generator=g18g)       # 7 text tokens
+    hid18[32:] = hid18[32:] * 1.5 + 0.3                   # the stylised branch differs in scale and offset from the style branch
+    g18 = dict(params=P18, hidden=hid18, enc=enc18)
+    with torch.no_grad():
+        o_img, o_txt = ref_sd3.CrossFrameProcessor()(attn18, hid18.clone(), enc18.clone())
+        m_img, m_txt = sd3_ref.joint_attention(P18, 2, hid18, enc18)
+        chk("sd3_g18_cross_frame_img", o_img, m_img)
+        chk("sd3_g18_cross_frame_txt", o_txt, m_txt)
+        g18["cross_frame"] = dict(img=o_img, txt=o_txt)
+        g18["cross_frame_no_text"] = ref_sd3.CrossFrameProcessor()(attn18, hid18.clone())
+        chk("sd3_g18_cross_frame_no_text", g18["cross_frame_no_text"], sd3_ref.joint_attention(P18, 2, hid18, None))
+        for idx in (0, 17, 30, 31):
+            proc = ref_sd3.AttentionShiftProcessor(0.0, 0.6)
+            proc.thresh2 = proc.eta2                     # the fixed reading (oracle/sd3_ref.py)
+            o_img, o_txt = proc(attn18, hid18.clone(), enc18.clone(), idx=idx)
+            m_img, m_txt = sd3_ref.joint_attention(P18, 2, hid18, enc18, idx=idx, shift=True, eta1=0.0, eta2=0.6)
+            chk(f"sd3_g18_shift_idx{idx}_img", o_img, m_img)
+            chk(f"sd3_g18_shift_idx{idx}_txt", o_txt, m_txt)
+            g18[f"shift_idx{idx}"] = dict(img=o_img, txt=o_txt)
+        kk18 = torch.randn(16, 2, 24, 64, generator=g18g)
+        ks18 = 0.4 + 1.7 * torch.randn(16, 2, 24, 64, generator=g18g)
+        g18["attention_adain"] = dict(cnt=kk18, sty=ks18, out=ref_sd3.attention_adain(kk18, ks18))
+        chk("sd3_g18_attention_adain", g18["attention_adain"]["out"], sd3_ref.attention_adain(kk18, ks18))
+    gold["g18_sd3_processors_hd64"] = g18
+
     for k, v in gold.items():
         torch.save(v, os.path.join(OUT, k + ".pt"))
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:

@@ -26,6 +26,12 @@ SURFACE = {
     "src.mask_propagation": ("univst_amd.src.mask_propagation", ["video_mask_propogation", "mask_propogation", "read_feature", "norm_mask",
                                                                  "to_one_hot"]),                                                            # mask_propagation.py:15-140
     "src.cal_optica_flow": ("univst_amd.src.cal_optica_flow", ["get_warp"]),                                                               # cal_optica_flow.py:51
+    # first vertical slice of the SD3 / SD3.5 path: the plugin's processors + helpers and the rectified-flow inversions
+    "backbones.video_diffusion_sd3.pnp_utils": ("univst_amd.backbones.video_diffusion_sd3.pnp_utils",
+                                                ["CrossFrameProcessor", "AttentionShiftProcessor", "register_spatial_attention_pnp",
+                                                 "attention_adain", "latent_adain"]),                                                      # video_diffusion_sd3/pnp_utils.py:9,135,276,289,305
+    "inversion_tools.flow_inversion": ("univst_amd.inversion_tools.flow_inversion",
+                                       ["rf_inversion", "rf_solver", "content_inversion_reconstruction", "style_inversion_reconstruction"]),  # flow_inversion.py:16-264
 }
 
 

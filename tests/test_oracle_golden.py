@@ -306,3 +306,19 @@ def test_sd3_rectified_flow_inversions(golden):
         return torch.tanh(0.7 * x.flip(-1)) * (0.5 + tt) - 0.3 * x + 0.05 * idx
     assert rel(sd3_ref.rf_inversion(vel, z0.clone(), sig, g["rf_inversion"]["noise"], 0.5)[-1], g["rf_inversion"]["final"]) < TOL
     assert rel(sd3_ref.rf_solver(vel, z0.clone(), sig)[-1], g["rf_solver"]["final"]) < TOL
+
+
+def test_sd3_processors_head_dim_64_g18(golden):
+    """G18: the reference's processors at a shape the native kernels serve (head_dim 64, 40 image + 13 text tokens) and its
+    attention_adain on [16, 2, 40, 64]; also the (parity-unpinned) JointTransformerBlock restatement runs on such shapes."""
+    from oracle import sd3_ref
+    g = golden("g18_sd3_processors_hd64")
+    P, hid, enc = g["params"], g["hidden"], g["enc"]
+    img, txt = sd3_ref.joint_attention(P, 2, hid, enc)
+    assert rel(img, g["cross_frame"]["img"]) < TOL and rel(txt, g["cross_frame"]["txt"]) < TOL
+    assert rel(sd3_ref.joint_attention(P, 2, hid, None), g["cross_frame_no_text"]) < TOL
+    for idx in (0, 17, 30, 31):
+        img, txt = sd3_ref.joint_attention(P, 2, hid, enc, idx=idx, shift=True, eta1=0.0, eta2=0.6)
+        assert rel(img, g[f"shift_idx{idx}"]["img"]) < TOL and rel(txt, g[f"shift_idx{idx}"]["txt"]) < TOL, idx
+    a = g["attention_adain"]
+    assert rel(sd3_ref.attention_adain(a["cnt"], a["sty"]), a["out"]) < TOL

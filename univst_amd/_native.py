@@ -26,6 +26,12 @@ class PnP(C.Structure):
                 ("alpha", C.c_float), ("gamma", C.c_float)]
 
 
+class Sd3AttnWeights(C.Structure):
+    _NAMES = ("to_q", "to_q_bias", "to_k", "to_k_bias", "to_v", "to_v_bias", "norm_q", "norm_k", "add_q", "add_q_bias", "add_k", "add_k_bias",
+              "add_v", "add_v_bias", "norm_added_q", "norm_added_k", "to_out", "to_out_bias", "to_add_out", "to_add_out_bias")
+    _fields_ = [(n, C.c_void_p) for n in _NAMES]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int)
 KVEXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
 
@@ -60,6 +66,11 @@ SIGNATURES = {
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
+    "univst_sd3_adain_shift": (_I, [_P, _L, _I, _I, _I, _I, _F, _F, _F, _P, _P]),
+    "univst_rmsnorm_heads": (_I, [_P, _L, _L, _I, _I, _P, _F, _P]),
+    "univst_adaln_modulate": (_I, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
+    "univst_axpbypcz": (_I, [_P, _P, _P, _P, _F, _F, _F, _L, _P]),
     "univst_attention_adain_shift": (_I, [_P, _L, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_latent_adain": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "univst_latent_adain_stats": (_I, [_P, _P, _I, _I, _I, _P]),
@@ -226,6 +237,66 @@ def attention(q, k, v, src_idx, heads, ldq=None, ldkv=None, Nq=None, Nkv=None, C
     check(load().univst_attention(ptr(q), ldq or q.stride(1), ptr(k), ptr(v), ldkv or k.stride(1), ptr(out), C_,
                                   ptr(src_idx), ptr(src_cnt), ptr(src_logw), src_idx.shape[1], BF, Nq_, Nkv or k.shape[1], heads, C_ // heads,
                                   int(bool(q_prescaled)), stream_ptr()), "attention")
+    return out
+
+
+_SD3_KEYS = {"to_q": "to_q.weight", "to_q_bias": "to_q.bias", "to_k": "to_k.weight", "to_k_bias": "to_k.bias", "to_v": "to_v.weight",
+             "to_v_bias": "to_v.bias", "norm_q": "norm_q.weight", "norm_k": "norm_k.weight", "add_q": "add_q_proj.weight",
+             "add_q_bias": "add_q_proj.bias", "add_k": "add_k_proj.weight", "add_k_bias": "add_k_proj.bias", "add_v": "add_v_proj.weight",
+             "add_v_bias": "add_v_proj.bias", "norm_added_q": "norm_added_q.weight", "norm_added_k": "norm_added_k.weight",
+             "to_out": "to_out.0.weight", "to_out_bias": "to_out.0.bias", "to_add_out": "to_add_out.weight", "to_add_out_bias": "to_add_out.bias"}
+
+
+def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False, idx=-1, eta1=0.0, eta2=0.6, rms_eps=1e-6):
+    """CrossFrameProcessor / AttentionShiftProcessor of the reference's SD3 plugin on the native kernels.  params: the state dict
+    of diffusers' Attention module (to_q.weight, ..., to_add_out.bias; missing entries = absent).  hidden [B, N, Cin],
+    enc [B, Nt, Cin] or None -> (img [B, N, Cin], txt [B, Nt, Cin]) or img alone."""
+    _f16(hidden)
+    B, N, Cin = hidden.shape
+    keep = {k: params[v].to(device=hidden.device, dtype=torch.float16).contiguous() for k, v in _SD3_KEYS.items() if params.get(v) is not None}
+    w = Sd3AttnWeights(**{k: (keep[k].data_ptr() if k in keep else None) for k in Sd3AttnWeights._NAMES})
+    inner = keep["to_q"].shape[0]
+    out_i = torch.empty_like(hidden)
+    Nt = 0
+    out_t = None
+    if enc is not None:
+        _f16(enc)
+        Nt = enc.shape[1]
+        out_t = torch.empty(B, Nt, Cin if "to_add_out" in keep else inner, device=hidden.device, dtype=torch.float16)
+    check(load().univst_sd3_joint_attention(C.byref(w), ptr(hidden), ptr(enc), B, N, Nt, Cin, heads, inner // heads, clip_length, int(bool(shift)),
+                                            int(idx), eta1, eta2, rms_eps, ptr(out_i), ptr(out_t), stream_ptr()), "sd3_joint_attention")
+    return (out_i, out_t) if enc is not None else out_i
+
+
+def sd3_adain_shift_(qkv, F, N, C_, heads, alpha, beta, gamma):
+    """in place on the fused [3*F*N, 3C] buffer (SD3 plugin's AdaIN shift)."""
+    _f16(qkv)
+    ws = torch.empty(4 * F * 2 * C_ + 2 * F * 2 * heads, device=qkv.device, dtype=torch.float32)
+    check(load().univst_sd3_adain_shift(ptr(qkv), qkv.shape[-1], F, N, C_, heads, alpha, beta, gamma, ptr(ws), stream_ptr()), "sd3_adain_shift")
+    return qkv
+
+
+def rmsnorm_heads_(x, heads, weight, eps=1e-6):
+    """in place on [rows, heads*d] fp16."""
+    _f16(x)
+    rows, Cc = x.shape
+    check(load().univst_rmsnorm_heads(ptr(x), x.stride(0), rows, heads, Cc // heads, ptr(weight), eps, stream_ptr()), "rmsnorm_heads")
+    return x
+
+
+def adaln_modulate(x, scale, shift, eps=1e-6):
+    """x [B, N, C], scale / shift [B, C] -> LayerNorm(x) * (1 + scale) + shift."""
+    _f16(x), _f16(scale), _f16(shift)
+    B, N, Cc = x.shape
+    out = torch.empty_like(x)
+    check(load().univst_adaln_modulate(ptr(x), ptr(out), ptr(scale), ptr(shift), B * N, N, Cc, eps, stream_ptr()), "adaln_modulate")
+    return out
+
+
+def axpbypcz(x, y, z, a, b, c, out=None):
+    _f16(x), _f16(y), _f16(z)
+    out = torch.empty_like(x) if out is None else out
+    check(load().univst_axpbypcz(ptr(x), ptr(y), ptr(z), ptr(out), a, b, c, x.numel(), stream_ptr()), "axpbypcz")
     return out
 
 

@@ -1,0 +1,88 @@
+"""Mirror of backbones/video_diffusion_sd3/pnp_utils.py of the reference — the SD3 / SD3.5 plugin's attention processors and AdaIN
+helpers — on the native kernels (first vertical slice of SURVEY §8f-4; csrc/sd3.hip).  Same class / function names and call
+signatures: the processors are handed diffusers' ``Attention`` module (they read its parameters, never call its layers) and return
+what the reference's ``__call__`` returns.  The MM-DiT that would call them (diffusers' SD3Transformer2DModel behind
+``models/transformer_3D_model.py``) is third-party and not part of this build: there is no SD3 backbone here yet.
+
+Known defect of the reference kept visible: ``AttentionShiftProcessor`` reads ``self.thresh2`` (pnp_utils.py:186), which nothing
+sets — the reference path raises AttributeError at HEAD.  This mirror implements the documented fixed reading ``thresh2 == eta2``
+(the only value for which beta runs 0.9 -> 0.1 across the window like the SD-v1.5 closure); oracle/sd3_ref.py and golden G16 pin it.
+"""
+import torch
+
+from ... import _native
+
+
+def _params(attn):
+    """state dict of the attention module the processor was handed (to_q.weight, ..., to_add_out.bias)."""
+    return {k: v for k, v in attn.state_dict().items()}
+
+
+def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2):
+    dt, dev = hidden_states.dtype, hidden_states.device
+    if dev.type != "cuda":
+        raise RuntimeError("univst_amd SD3 processors run on the GPU only (no CPU path): move the tensors to cuda")
+    hid = hidden_states.to(torch.float16).contiguous()
+    enc = None if encoder_hidden_states is None else encoder_hidden_states.to(torch.float16).contiguous()
+    eps = getattr(getattr(attn, "norm_q", None), "eps", None) or 1e-6
+    out = _native.sd3_joint_attention(_params(attn), hid, enc, attn.heads, clip_length=16, shift=shift, idx=idx, eta1=eta1, eta2=eta2,
+                                      rms_eps=float(eps))
+    if enc is None:
+        return out.to(dt)
+    return out[0].to(dt), out[1].to(dt)
+
+
+class CrossFrameProcessor:
+    """pnp_utils.py:9-131: joint attention whose image keys / values are those of frames ['first', f-1, f] of the clip."""
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, **kwargs):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is not used on the UniVST path")
+        return _run(attn, hidden_states, encoder_hidden_states, False, idx, 0.0, 0.0)
+
+
+class AttentionShiftProcessor:
+    """pnp_utils.py:134-271: the same with the AdaIN-guided shift of the stylised branch inside eta1*50 <= idx <= eta2*50."""
+
+    def __init__(self, eta1, eta2):
+        self.eta1, self.eta2 = eta1, eta2
+        self.thresh2 = eta2          # the attribute the reference forgets to set (see the module docstring)
+
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, **kwargs):
+        if attention_mask is not None:
+            raise NotImplementedError("attention_mask is not used on the UniVST path")
+        return _run(attn, hidden_states, encoder_hidden_states, True, idx, self.eta1, self.thresh2)
+
+
+def register_spatial_attention_pnp(model, eta1=0.0, eta2=0.6):
+    """pnp_utils.py:276-286."""
+    new_procs = {}
+    for name, processor in model.transformer.attn_processors.items():
+        new_procs[name] = AttentionShiftProcessor(eta1, eta2) if "attn" in name else processor
+    model.transformer.set_attn_processor(new_procs)
+
+
+def attention_adain(cnt_feat, sty_feat, ad=True):
+    """pnp_utils.py:289-302 on [B, heads, N, d]: F.instance_norm over (N, d) jointly per (batch, head), re-coloured with the style's
+    per-channel mean / unbiased std over N.  The shift kernel with alpha = 0, beta = 1, gamma = 1 (pure AdaIN of K) on a scratch
+    q | k | v buffer whose style / stylised K slices are filled."""
+    B, heads, N, d = cnt_feat.shape
+    dev = cnt_feat.device
+    C = heads * d
+    buf = torch.zeros(3 * B, N, 3 * C, dtype=torch.float16, device="cuda")
+    buf[B:2 * B, :, C:2 * C] = sty_feat.permute(0, 2, 1, 3).reshape(B, N, C).to("cuda")
+    buf[2 * B:, :, C:2 * C] = cnt_feat.permute(0, 2, 1, 3).reshape(B, N, C).to("cuda")
+    _native.sd3_adain_shift_(buf.view(3 * B * N, 3 * C), B, N, C, heads, 0.0, 1.0, 1.0)
+    return buf[2 * B:, :, C:2 * C].reshape(B, N, heads, d).permute(0, 2, 1, 3).to(device=dev, dtype=cnt_feat.dtype)
+
+
+def latent_adain(cnt_feat, sty_feat, ad=True):
+    """pnp_utils.py:305-316 on [B, C, H, W] (frames are the batch): per (frame, channel) statistics over (H, W) — the SD-v1.5
+    latent_adain kernel applied frame by frame ([1, C, 1, H, W] views)."""
+    dev, dt = cnt_feat.device, cnt_feat.dtype
+    c = cnt_feat.to(device="cuda", dtype=torch.float16)
+    s = sty_feat.to(device="cuda", dtype=torch.float16)
+    out = torch.empty_like(c)
+    for f in range(c.shape[0]):
+        out[f] = _native.latent_adain(c[f][None, :, None].contiguous(), s[f][None, :, None].contiguous())[0, :, 0]
+    return out.to(device=dev, dtype=dt)

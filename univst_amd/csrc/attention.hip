@@ -111,30 +111,38 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
         return v;
     };
     const int nsrc_eff = p.src_cnt ? p.src_cnt[bf] : p.nsrc;
-    const int T = nsrc_eff * ntile;
+    // the optional extra key segment (AttnParams::kx) follows the nsrc_eff equal-length sources as "source nsrc_eff" with its own
+    // length, row stride and buffers
+    const int ntile_x = p.kx ? (p.Nkv_x + KT - 1) / KT : 0;
+    const int T = nsrc_eff * ntile + ntile_x;
     int nx_s = 0, nx_t = 0;               // (source, tile-in-source) of the NEXT tile to load
     long nx_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc]) * p.Nkv * p.ldkv;      // element offset of that source's first key row
     bool ld_tail = false;                 // the tile in the prefetch registers has rows past Nkv (zeroed at store time)
-    int ld_t0 = 0;
+    int ld_t0 = 0, ld_nkv = p.Nkv;
     auto load_tile = [&]() {              // global -> registers; completes under the MFMAs of the current tile
+        const bool xs = nx_s >= nsrc_eff;                    // block-uniform: this tile belongs to the extra segment
+        const int nkv = xs ? p.Nkv_x : p.Nkv;
+        const long ld = xs ? p.ldkv_x : p.ldkv;
         const int t0 = nx_t * KT;
-        const half_t* kb = p.k + nx_off + (long)t0 * p.ldkv;
-        const half_t* vb = p.v + nx_off + (long)t0 * p.ldkv;
-        ld_tail = t0 + KT > p.Nkv;
+        const half_t* kb = (xs ? p.kx : p.k) + nx_off + (long)t0 * ld;
+        const half_t* vb = (xs ? p.vx : p.v) + nx_off + (long)t0 * ld;
+        ld_tail = t0 + KT > nkv;
         ld_t0 = t0;
-        const int rmax = p.Nkv - 1 - t0;
+        ld_nkv = nkv;
+        const int rmax = nkv - 1 - t0;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             if (i + 1 < NL || wave_u * 64 < REM) {
                 const int r = ld_tail ? (srow[i] < rmax ? srow[i] : rmax) : srow[i];      // clamp: never read past the source
-                const unsigned off = (unsigned)(r * (int)p.ldkv) + gcol[i];
+                const unsigned off = (unsigned)(r * (int)ld) + gcol[i];
                 kr[i] = gload16(kb + off);
                 vr[i] = gload16(vb + off);
             }
         }
-        if (++nx_t == ntile) {            // source boundary (<= nsrc-1 times per block): fetch the next source frame index
+        if (++nx_t == (xs ? ntile_x : ntile)) {            // source boundary (<= nsrc times per block): fetch the next source frame index
             nx_t = 0;
             if (++nx_s < nsrc_eff) nx_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc + nx_s]) * p.Nkv * p.ldkv;
+            else if (nx_s == nsrc_eff && ntile_x) nx_off = (long)__builtin_amdgcn_readfirstlane(p.x_idx[bf]) * p.Nkv_x * p.ldkv_x;
         }
     };
     auto store_tile = [&](half_t* buf) {
@@ -143,7 +151,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
         for (int i = 0; i < NL; ++i) {
             if (i + 1 < NL || wave_u * 64 < REM) {
                 asm volatile("" : "+v"(kr[i]), "+v"(vr[i]));          // the registers are defined from here on
-                if (ld_tail && ld_t0 + srow[i] >= p.Nkv) { kr[i] = zero8; vr[i] = zero8; }
+                if (ld_tail && ld_t0 + srow[i] >= ld_nkv) { kr[i] = zero8; vr[i] = zero8; }
                 *reinterpret_cast<h8*>(&buf[ksoff[i]]) = kr[i];
                 *reinterpret_cast<h8*>(&buf[vsoff[i]]) = vr[i];
             }
@@ -166,6 +174,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     __syncthreads();
 
     int cur_s = 0, cur_t = 0;             // (source, tile-in-source) of the tile being consumed
+    int cur_nkv = p.Nkv, cur_ntile = ntile;
     float lw = p.src_logw ? p.src_logw[bf * p.nsrc] : 0.f;            // log2 multiplicity of the current source ...
     float lwr = lw * (1.f / c);                                       // ... in raw-score units
     for (int tt = 0; tt < T; ++tt) {
@@ -190,14 +199,14 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
                     sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, qf[qb][ks], sc[kb][qb], 0, 0, 0);
             }
         }
-        if (t0 + KT > p.Nkv) {            // tail tile: mask keys beyond Nkv (block-uniform branch)
+        if (t0 + KT > cur_nkv) {          // tail tile: mask keys beyond the source's length (block-uniform branch)
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (t0 + kb * 16 + g * 4 + r >= p.Nkv) sc[kb][qb][r] = -INFINITY;
+                        if (t0 + kb * 16 + g * 4 + r >= cur_nkv) sc[kb][qb][r] = -INFINITY;
         }
         h8 pb[QB][2];
 #pragma unroll
@@ -279,11 +288,18 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
         if (!DBUF) __syncthreads();      // everyone finished reading the single buffer
         if (tt + 1 < T) store_tile(smem + (DBUF ? ((tt + 1) & 1) * TILE : 0));
         __syncthreads();
-        if (++cur_t == ntile) {
+        if (++cur_t == cur_ntile) {
             cur_t = 0;
-            if (++cur_s < nsrc_eff && p.src_logw) {
-                lw = p.src_logw[bf * p.nsrc + cur_s];
-                lwr = lw * (1.f / c);
+            if (++cur_s < nsrc_eff) {
+                if (p.src_logw) {
+                    lw = p.src_logw[bf * p.nsrc + cur_s];
+                    lwr = lw * (1.f / c);
+                }
+            } else {                      // the extra segment: its own length, multiplicity 1
+                cur_nkv = p.Nkv_x;
+                cur_ntile = ntile_x;
+                lw = 0.f;
+                lwr = 0.f;
             }
         }
     }
@@ -997,7 +1013,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         // UNIVST_ATTN_PP (A/B aid): 2 = software-pipelined kernel with scale/max folded into the MFMA when q is prescaled
         // (default; plain q takes attn_body), 1 = software-pipelined with plain softmax arithmetic, 0 = attn_body
         static const int pp = getenv("UNIVST_ATTN_PP") ? atoi(getenv("UNIVST_ATTN_PP")) : 2;
-        if (p.Nq >= 2048 && ((pp == 2 && p.q_prescaled) || pp == 1)) {
+        if (!p.kx && p.Nq >= 2048 && ((pp == 2 && p.q_prescaled) || pp == 1)) {
             const int nqb4 = (p.Nq + 255) / 256;
             const bool text = p.nsrc == 1 && p.Nkv <= 128;
             // UNIVST_ATTN_STG (A/B aid): 1 = K/V ring filled by LDS-DMA (default), 0 = through registers
@@ -1045,6 +1061,7 @@ int uv_launch_attention(const AttnParams& p0, hipStream_t stream) {
     UV_REQUIRE(p.d % 8 == 0, "attention: head_dim=%d must be a multiple of 8", p.d);
     UV_REQUIRE(p.nsrc >= 1 && p.Nkv >= 1 && p.Nq >= 1, "attention: empty problem");
     UV_REQUIRE(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must be multiples of 8");
+    UV_REQUIRE(!p.kx || (p.vx && p.x_idx && p.Nkv_x >= 1 && p.ldkv_x % 8 == 0), "attention: extra key segment needs vx, x_idx, Nkv_x >= 1 and a row stride that is a multiple of 8");
     const double nkv = (double)p.nsrc * p.Nkv;
     const int cls = (p.nsrc == 1 && p.Nkv <= 128) ? UV_CLS_ATTN_TEXT
                     : (p.d == 40 && p.Nq >= 2048) ? UV_CLS_ATTN_D40 : (p.d == 80 ? UV_CLS_ATTN_D80 : UV_CLS_ATTN_OTHER);
@@ -1058,7 +1075,7 @@ int uv_launch_attention(const AttnParams& p0, hipStream_t stream) {
 static int attn_dispatch(const AttnParams& p, hipStream_t stream) {
     // text cross-attention: one short source, K/V held in registers (attn_text_kernel).  UNIVST_ATTN_TEXT=0: generic kernels (A/B aid)
     static const int text_env = getenv("UNIVST_ATTN_TEXT") ? atoi(getenv("UNIVST_ATTN_TEXT")) : 1;
-    if (text_env && p.nsrc == 1 && p.Nkv <= 80 && !p.src_logw && (p.d == 40 || p.d == 80) && p.Nq >= 256) {
+    if (text_env && !p.kx && p.nsrc == 1 && p.Nkv <= 80 && !p.src_logw && (p.d == 40 || p.d == 80) && p.Nq >= 256) {
         const int nchunk = (p.Nq + 1023) / 1024;
         const dim3 grid((unsigned)(nchunk * p.heads * p.BF));
         if (p.d == 40) hipLaunchKernelGGL((attn_text_kernel<40>), grid, dim3(256), 0, stream, p);

@@ -60,6 +60,14 @@ struct AttnParams {
     float scale_log2e = 0.f;
     int q_prescaled = 0;            // q rows already carry the factor scale_log2e (the UNet graph folds it into to_q for head_dim 40)
     int order = 1;                  // d = 40 pipelined kernel: 1 = head-major block order (L2 reuse of shared key frames), 0 = frame-major
+    // one EXTRA key segment of its own length behind the equal-length sources (the text tokens of SD3's joint attention,
+    // video_diffusion_sd3/pnp_utils.py:80-98: keys = [first | prev | cur] image tokens ++ text tokens): rows x_idx[bf] * Nkv_x ..
+    // of kx / vx, head h at column h*d, no multiplicity.  Served by the generic kernel (attn_body) only.
+    const half_t* kx = nullptr;
+    const half_t* vx = nullptr;
+    const int* x_idx = nullptr;     // [BF] row block of the extra segment for every query frame
+    long ldkv_x = 0;
+    int Nkv_x = 0;
 };
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);

@@ -1,0 +1,262 @@
+// First vertical slice of the SD3 / SD3.5 rectified-flow path (BASELINE config 5): the pieces the REFERENCE owns —
+// its two joint-attention processors and the rectified-flow inversion updates — on the native kernels.  The MM-DiT around them
+// (diffusers' SD3Transformer2DModel) is third-party and not built; nothing here claims a backbone.
+//
+//   uv_sd3_joint_attention   CrossFrameProcessor (video_diffusion_sd3/pnp_utils.py:17-131) and AttentionShiftProcessor (:143-271,
+//                            under the documented fixed reading thresh2 == eta2, oracle/sd3_ref.py): q/k/v + added q/k/v
+//                            projections (MFMA GEMMs), per-head RMSNorm of q / k, the AdaIN-guided shift of the stylised branch,
+//                            cross-frame K/V ['first', f-1, f] read BY POINTER plus the text tokens as one extra key segment of
+//                            its own length (AttnParams::kx), output projections.
+//   rms_heads_kernel         diffusers RMSNorm over the head dim (qk_norm = "rms_norm"), in place on a [rows, heads*d] slice
+//   sd3 AdaIN shift          F.instance_norm on [B, heads, N, d] normalises over (N, d) JOINTLY per (frame, head) (biased variance,
+//                            eps 1e-5), re-coloured with the style branch's per-(frame, head, channel) mean / unbiased std over N
+//   adaln_modulate_kernel    LayerNorm(no affine) * (1 + scale[b]) + shift[b]  (AdaLayerNormZero / AdaLayerNormContinuous)
+//   axpbypcz                 the three-term updates of rf_inversion / rf_solver (inversion_tools/flow_inversion.py:123-264)
+#include <math.h>
+
+#include "common.h"
+#include "kernels.h"
+#include "../../include/univst.h"
+
+namespace {
+
+// one wave per (row, head): x <- x * rsqrt(mean(x^2) + eps) * w      (d <= 256, multiple of 2)
+__global__ __launch_bounds__(256) void rms_heads_kernel(half_t* __restrict__ x, long ld, long rows, int heads, int d,
+                                                        const half_t* __restrict__ w, float eps) {
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (unit >= rows * heads) return;
+    const long r = unit / heads;
+    const int h = (int)(unit - r * heads);
+    half_t* p = x + r * ld + (long)h * d;
+    float v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        v[i] = e < d ? (float)p[e] : 0.f;
+        ss += v[i] * v[i];
+    }
+    const float r_ = rsqrtf(wave_sum(ss) / d + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = lane + 64 * i;
+        if (e < d) p[e] = (half_t)(v[i] * r_ * (float)w[e]);
+    }
+}
+
+// per (frame, t in {K, V}, head): (mu, rstd) of the stylised branch over (N, d) jointly, from its per-column statistics
+// (colstats: mean_c, unbiased std_c over the N rows): sum_n x^2 = (N-1) std_c^2 + N mean_c^2
+__global__ void sd3_group_stats_kernel(const float* __restrict__ mean, const float* __restrict__ stdv, int F, int N, int C, int heads,
+                                       float* __restrict__ mu, float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (f, t, h)
+    if (i >= F * 2 * heads) return;
+    const int d = C / heads;
+    const float* m = mean + (long)i * d;                       // columns of [F][2C] are (t, h, e)-major: i*d is exactly (f, t, h, 0)
+    const float* s = stdv + (long)i * d;
+    double a = 0.0, b = 0.0;
+    for (int e = 0; e < d; ++e) {
+        const double me = m[e], se = s[e];
+        a += me;
+        b += (double)(N - 1) * se * se + (double)N * me * me;
+    }
+    const double mean_g = a / d;
+    double var = b / ((double)N * d) - mean_g * mean_g;
+    if (var < 0.0) var = 0.0;
+    mu[i] = (float)mean_g;
+    rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+// the shift itself, one wave per token row of the stylised branch (rows [2*F*N, 3*F*N) of the fused [3*F*N, 3C] q|k|v buffer):
+//   q2 <- gamma * (alpha * q0 + (1 - alpha) * q2)
+//   k2 <- beta * ((k2 - mu) * rstd * sty_std + sty_mean) + (1 - beta) * k1        (same for v)
+__global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv, long ld, int F, int N, int C, int heads,
+                                                        const float* __restrict__ smean, const float* __restrict__ sstd,
+                                                        const float* __restrict__ mu, const float* __restrict__ rstd, float alpha,
+                                                        float beta, float gamma) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const long FN = (long)F * N;
+    if (r >= FN) return;
+    const int f = (int)(r / N), d = C / heads;
+    half_t* row0 = qkv + r * ld;
+    half_t* row1 = qkv + (FN + r) * ld;
+    half_t* row2 = qkv + (2 * FN + r) * ld;
+    for (int c = lane; c < C; c += 64) row2[c] = (half_t)(gamma * (alpha * (float)row0[c] + (1.f - alpha) * (float)row2[c]));
+    for (int t = 0; t < 2; ++t) {
+        const int off = (1 + t) * C;
+        for (int c = lane; c < C; c += 64) {
+            const int gi = (f * 2 + t) * heads + c / d;
+            const long ci = ((long)f * 2 + t) * C + c;
+            const float ad = ((float)row2[off + c] - mu[gi]) * rstd[gi] * sstd[ci] + smean[ci];
+            row2[off + c] = (half_t)(beta * ad + (1.f - beta) * (float)row1[off + c]);
+        }
+    }
+}
+
+// src_idx [B][3] = ['first', f-1 (clipped), f] of the frame's own clip, x_idx [B] = the frame itself (pnp_utils.py:27,53-78)
+__global__ void sd3_index_kernel(int B, int clip, int* __restrict__ src_idx, int* __restrict__ x_idx) {
+    const int bf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bf >= B) return;
+    const int b = bf / clip, f = bf - b * clip;
+    src_idx[bf * 3 + 0] = b * clip;
+    src_idx[bf * 3 + 1] = b * clip + (f > 0 ? f - 1 : 0);
+    src_idx[bf * 3 + 2] = bf;
+    x_idx[bf] = bf;
+}
+
+// y = LN(x) * (1 + scale[b]) + shift[b]; one wave per row, C <= 4096
+__global__ __launch_bounds__(256) void adaln_modulate_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const half_t* __restrict__ scale,
+                                                             const half_t* __restrict__ shift, long rows, long rows_per_batch, int C, float eps) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const long b = r / rows_per_batch;
+    const half_t* xr = x + r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += (float)xr[c];
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float dl = (float)xr[c] - mu;
+        q += dl * dl;
+    }
+    const float rs = rsqrtf(wave_sum(q) / C + eps);
+    for (int c = lane; c < C; c += 64)
+        y[r * C + c] = (half_t)(((float)xr[c] - mu) * rs * (1.f + (float)scale[b * C + c]) + (float)shift[b * C + c]);
+}
+
+__global__ void axpbypcz_kernel(const half_t* __restrict__ x, const half_t* __restrict__ y, const half_t* __restrict__ z,
+                                half_t* __restrict__ out, float a, float b, float c, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (half_t)(a * (float)x[i] + b * (float)y[i] + c * (float)z[i]);
+}
+
+int linear(const half_t* X, long ldx, long M, int K, const half_t* W, const half_t* b, int N, half_t* Y, long ldy, hipStream_t s) {
+    GemmParams g;
+    g.X = X; g.ldx = ldx; g.M = (int)M; g.K = K; g.N = N; g.W = W; g.bias = b; g.Y = Y; g.ldy = ldy;
+    return uv_launch_gemm(g, 0, s);
+}
+
+}  // namespace
+
+#define RUN(x)                \
+    do {                      \
+        int _rc = (x);        \
+        if (_rc) return _rc;  \
+    } while (0)
+
+extern "C" {
+
+int univst_rmsnorm_heads(void* x, int64_t ld, int64_t rows, int heads, int d, const void* weight, float eps, void* stream) {
+    UV_REQUIRE(x && weight && rows >= 1 && heads >= 1 && d >= 1 && d <= 256, "rmsnorm_heads: bad argument (head_dim <= 256)");
+    hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (half_t*)x, ld, rows, heads, d,
+                       (const half_t*)weight, eps);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t rows, int64_t rows_per_batch, int C, float eps,
+                          void* stream) {
+    UV_REQUIRE(x && y && scale && shift && rows >= 1 && rows_per_batch >= 1 && C >= 1, "adaln_modulate: bad argument");
+    hipLaunchKernelGGL(adaln_modulate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y,
+                       (const half_t*)scale, (const half_t*)shift, rows, rows_per_batch, C, eps);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_axpbypcz(const void* x, const void* y, const void* z, void* out, float a, float b, float c, int64_t n, void* stream) {
+    UV_REQUIRE(x && y && z && out && n >= 1, "axpbypcz: bad argument");
+    hipLaunchKernelGGL(axpbypcz_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (const half_t*)y,
+                       (const half_t*)z, (half_t*)out, a, b, c, n);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+// in place on the fused [3*F*N, 3C] q | k | v buffer (row stride ld; branch 0 content, 1 style, 2 stylised); ws: 4*F*2C + 2*F*2*heads floats
+int univst_sd3_adain_shift(void* qkv, int64_t ld, int F, int N, int C, int heads, float alpha, float beta, float gamma, void* ws, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    UV_REQUIRE(qkv && ws && F >= 1 && N >= 2 && heads >= 1 && C % heads == 0 && C % 8 == 0, "sd3_adain_shift: bad argument");
+    half_t* q = (half_t*)qkv;
+    float *smean = (float*)ws, *sstd = smean + (long)F * 2 * C, *cmean = sstd + (long)F * 2 * C, *cstd = cmean + (long)F * 2 * C;
+    float *mu = cstd + (long)F * 2 * C, *rstd = mu + (long)F * 2 * heads;
+    const long FN = (long)F * N;
+    RUN(uv_launch_colstats(q + FN * ld + C, ld, F, N, 2 * C, smean, sstd, s));           // style branch K | V: per (frame, channel) over N
+    RUN(uv_launch_colstats(q + 2 * FN * ld + C, ld, F, N, 2 * C, cmean, cstd, s));       // stylised branch K | V
+    hipLaunchKernelGGL(sd3_group_stats_kernel, dim3((unsigned)((F * 2 * heads + 127) / 128)), dim3(128), 0, s, cmean, cstd, F, N, C, heads, mu, rstd);
+    hipLaunchKernelGGL(sd3_shift_kernel, dim3((unsigned)((FN + 3) / 4)), dim3(256), 0, s, q, (long)ld, F, N, C, heads, smean, sstd, mu, rstd, alpha,
+                       beta, gamma);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin, int heads,
+                               int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps, void* out_img,
+                               void* out_txt, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    UV_REQUIRE(w && hidden && out_img && B >= 1 && N >= 1 && heads >= 1, "sd3_joint_attention: null / empty argument");
+    UV_REQUIRE(w->to_q && w->to_k && w->to_v && w->to_out, "sd3_joint_attention: to_q / to_k / to_v / to_out weights are required");
+    UV_REQUIRE(clip_length >= 1 && B % clip_length == 0, "sd3_joint_attention: batch %d is not a whole number of %d-frame clips", B, clip_length);
+    UV_REQUIRE(!shift || B % 3 == 0, "sd3_joint_attention: the attention shift needs the three-branch batch");
+    UV_REQUIRE(!enc || (out_txt && Nt >= 1 && w->add_q && w->add_k && w->add_v), "sd3_joint_attention: text tokens need add_{q,k,v}_proj and out_txt");
+    const int C = heads * head_dim;
+    UV_REQUIRE(Cin % 8 == 0 && C % 8 == 0, "sd3_joint_attention: widths must be multiples of 8");
+    const long rows_i = (long)B * N, rows_t = enc ? (long)B * Nt : 0;
+    // one stream-ordered scratch block: qkv_img [rows_i, 3C] | qkv_txt [rows_t, 3C] | o_img [rows_i, C] | o_txt [rows_t, C] | stats | index tables
+    const int Fb = B / 3;                                    // frames per branch (shift only)
+    const size_t n_half = (size_t)(rows_i + rows_t) * 4 * C;
+    const size_t n_stat = shift ? (size_t)4 * Fb * 2 * C + (size_t)2 * Fb * 2 * heads : 0;
+    char* ws = nullptr;
+    const size_t bytes = n_half * sizeof(half_t) + n_stat * sizeof(float) + (size_t)B * 4 * sizeof(int) + 1024;
+    UV_HIP(hipMallocAsync((void**)&ws, bytes, s));
+    half_t* qkv_i = (half_t*)ws;
+    half_t* qkv_t = qkv_i + rows_i * 3 * C;
+    half_t* o_i = qkv_t + rows_t * 3 * C;
+    half_t* o_t = o_i + rows_i * C;
+    float* st = (float*)(((uintptr_t)(o_t + rows_t * C) + 255) & ~(uintptr_t)255);
+    int* tab = (int*)(st + n_stat);
+    auto H = [](const void* p) { return (const half_t*)p; };
+    int rc = UV_OK;
+    auto body = [&]() -> int {
+        const half_t* x = H(hidden);
+        RUN(linear(x, Cin, rows_i, Cin, H(w->to_q), H(w->to_q_bias), C, qkv_i, 3 * C, s));
+        RUN(linear(x, Cin, rows_i, Cin, H(w->to_k), H(w->to_k_bias), C, qkv_i + C, 3 * C, s));
+        RUN(linear(x, Cin, rows_i, Cin, H(w->to_v), H(w->to_v_bias), C, qkv_i + 2 * C, 3 * C, s));
+        if (w->norm_q) RUN(univst_rmsnorm_heads(qkv_i, 3 * C, rows_i, heads, head_dim, w->norm_q, rms_eps, s));
+        if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
+        if (shift && (float)idx >= eta1 * 50.f && (float)idx <= eta2 * 50.f) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0)
+            const float beta = (0.9f - 0.1f) / (eta1 * 50.f - eta2 * 50.f) * ((float)idx - eta2 * 50.f) + 0.1f;
+            RUN(univst_sd3_adain_shift(qkv_i, 3 * C, Fb, N, C, heads, 0.8f, beta, 2.0f, st, s));
+        }
+        if (enc) {
+            const half_t* e = H(enc);
+            RUN(linear(e, Cin, rows_t, Cin, H(w->add_q), H(w->add_q_bias), C, qkv_t, 3 * C, s));
+            RUN(linear(e, Cin, rows_t, Cin, H(w->add_k), H(w->add_k_bias), C, qkv_t + C, 3 * C, s));
+            RUN(linear(e, Cin, rows_t, Cin, H(w->add_v), H(w->add_v_bias), C, qkv_t + 2 * C, 3 * C, s));
+            if (w->norm_added_q) RUN(univst_rmsnorm_heads(qkv_t, 3 * C, rows_t, heads, head_dim, w->norm_added_q, rms_eps, s));
+            if (w->norm_added_k) RUN(univst_rmsnorm_heads(qkv_t + C, 3 * C, rows_t, heads, head_dim, w->norm_added_k, rms_eps, s));
+        }
+        hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, tab, tab + 3 * B);
+        UV_LAUNCH_CHECK();
+        AttnParams a;
+        a.k = qkv_i + C; a.v = qkv_i + 2 * C; a.ldkv = 3 * C;
+        a.src_idx = tab; a.nsrc = 3; a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
+        a.scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+        if (enc) { a.kx = qkv_t + C; a.vx = qkv_t + 2 * C; a.ldkv_x = 3 * C; a.Nkv_x = Nt; a.x_idx = tab + 3 * B; }
+        a.q = qkv_i; a.ldq = 3 * C; a.Nq = N; a.o = o_i; a.ldo = C;
+        RUN(uv_launch_attention(a, s));                                  // image queries over [first | prev | cur] ++ text keys
+        RUN(linear(o_i, C, rows_i, C, H(w->to_out), H(w->to_out_bias), Cin, (half_t*)out_img, Cin, s));
+        if (enc) {
+            a.q = qkv_t; a.Nq = Nt; a.o = o_t;
+            RUN(uv_launch_attention(a, s));                              // text queries over the same key set
+            if (w->to_add_out) RUN(linear(o_t, C, rows_t, C, H(w->to_add_out), H(w->to_add_out_bias), Cin, (half_t*)out_txt, Cin, s));
+            else UV_HIP(hipMemcpyAsync(out_txt, o_t, (size_t)rows_t * C * sizeof(half_t), hipMemcpyDeviceToDevice, s));      // context_pre_only
+        }
+        return UV_OK;
+    };
+    rc = body();
+    (void)hipFreeAsync(ws, s);
+    return rc;
+}
+
+}  // extern "C"
