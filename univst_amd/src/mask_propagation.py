@@ -62,15 +62,17 @@ def mask_propogation(feat_src_rows, feat_tar, segs, args):
     _native.check(lib.univst_maskprop_frame(feat_tar.data_ptr(), feat_src_rows.data_ptr(), segs.contiguous().data_ptr(),
                                             segs_tar.data_ptr(), hw, Nsrc, C_, ncls, float(args.temperature), int(args.topk),
                                             ws.data_ptr(), _native.stream_ptr()), "maskprop_frame")
-    fg = segs_tar[0, :] != 0
-    fore_index = torch.where(fg)[0].cpu()
-    back_index = torch.where(~fg)[0].cpu()
-    fn, bn = len(fore_index), len(back_index)
-    ri = torch.randperm(fn)[: int(fn * fn / (fn + bn) * args.sample_ratio)]
-    fs = fore_index[ri]
-    ri = torch.randperm(bn)[: int(bn * bn / (fn + bn) * args.sample_ratio)]
-    bs = back_index[ri]
-    all_index = torch.cat([fs, bs]).to(dev)
+    # mask_propagation.py:87-97.  The two torch.randperm calls must see the reference's (fn, bn) in the reference's order on the
+    # HOST generator (same index stream), so one number per frame has to come back from the device: fn.  Everything else stays
+    # there: a stable argsort of the background flag lists the foreground positions ascending, then the background ones — what
+    # torch.where(fg)[0] / torch.where(~fg)[0] return — without the two nonzero() syncs and index-list round trips of round 2.
+    bg = segs_tar[0, :] == 0
+    order = torch.argsort(bg.to(torch.uint8), stable=True)
+    fn = hw - int(bg.sum().item())
+    bn = hw - fn
+    ri_f = torch.randperm(fn)[: int(fn * fn / (fn + bn) * args.sample_ratio)]
+    ri_b = torch.randperm(bn)[: int(bn * bn / (fn + bn) * args.sample_ratio)]
+    all_index = order[torch.cat([ri_f, ri_b + fn]).to(dev, non_blocking=True)]
     return segs_tar, feat_tar[all_index].contiguous(), segs_tar[:, all_index].contiguous()
 
 
@@ -106,7 +108,10 @@ def propagate_masks(features, first_mask_u8, args):
         if len(que) == args.n_last_frames:
             que.popleft()
         que.append([fs, ss])
-        out.append(norm_argmax_mask(final, h, w, ori_h, ori_w).cpu().numpy())
+        out.append(norm_argmax_mask(final, h, w, ori_h, ori_w))
+    if len(out) > 1:         # one device -> host copy for the whole clip instead of a blocking copy per frame
+        rest = torch.stack(out[1:]).cpu().numpy()
+        out = [out[0]] + [rest[i] for i in range(rest.shape[0])]
     return out
 
 
