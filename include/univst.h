@@ -61,7 +61,10 @@ int univst_unet_destroy(univst_unet* h);
 int univst_unet_load_tensor(univst_unet* h, const char* key, const void* dev_ptr, int dtype, const int64_t* shape,
                             int ndim, void* stream);
 /* builds the derived weight layouts ([Cout][ky][kx][Cin] convs, fused QKV / KV, GEGLU-interleaved FF) and
- * verifies that the *_temporal* layers are the identity/bias-only initialisation (else UNIVST_ERR_UNSUPPORTED) */
+ * inspects the *_temporal* layers on the device: units still at their identity initialisation (dirac conv1d, zero
+ * attn_temporal.to_out: every 2-D-initialised checkpoint) are skipped exactly; TRAINED units (a fine-tuned 3-D checkpoint) get their
+ * derived layouts and run (resnet.py:70-80 as a 3-tap conv over frames through the conv kernels, attention.py:336-346 in a frame
+ * attention kernel).  Trained temporal layers and frame sharding exclude each other (forward returns UNIVST_ERR_ARG). */
 int univst_unet_finalize(univst_unet* h, void* stream);
 /* (re)allocates the activation arena for this geometry; forward() calls it implicitly on first use */
 int univst_unet_reserve(univst_unet* h, int B, int F, int H, int W);

@@ -376,3 +376,41 @@ def test_f16_pixel_smoother_leg_vs_oracle_on_device(sd15):
     assert torch.equal(plain[19], got[19]) and not torch.equal(plain[20], got[20])
     assert all(v >= 40.0 for v in vals.values()), vals
     assert all(vals[f"i{i}"] >= off[f"i{i}"] + 6.0 for i in (20, 21, 22, 23, 24)), (vals, off)
+
+
+def test_trained_temporal_layers_at_sd15_widths_vs_oracle_on_device():
+    """a fine-tuned 3-D checkpoint at SD-v1.5 widths (320 .. 1280 channels, head dims 40 / 80 / 160): every conv_temporal perturbed
+    away from the dirac kernel, every attn_temporal.to_out away from zero — three branches x 4 frames x 32x32 latents inside the PnP
+    window, native graph (Conv1d over frames through the implicit-GEMM conv kernels, frame attention kernel) vs the oracle's exact
+    temporal path in fp32 on the device (oracle pinned to the reference's modules by G4 / G5-general).  Same bar as the 2-D forward:
+    max <= 5e-3 of max|ref|, relative RMS <= 3e-3; and the run must differ clearly from the identity-initialised one."""
+    from univst_amd import synth
+    from univst_amd.backbones.video_diffusion_sd import pnp_utils
+    unet = synth.build_unet(device="cuda", seed=17)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    with torch.no_grad():
+        for name, p_ in unet.named_parameters():
+            if "conv_temporal.weight" in name:
+                p_.add_((0.35 / math.sqrt(3 * p_.shape[1])) * torch.randn(p_.shape, generator=g, device="cuda").to(p_))
+            elif "conv_temporal.bias" in name:
+                p_.add_(0.02 * torch.randn(p_.shape, generator=g, device="cuda").to(p_))
+            elif "attn_temporal.to_out.0.weight" in name:
+                p_.add_((0.5 / math.sqrt(p_.shape[1])) * torch.randn(p_.shape, generator=g, device="cuda").to(p_))
+    sd = {k: v.float() for k, v in unet.state_dict().items()}
+    cfg = unet_ref.SD15_CONFIG
+    F_ = 4
+    gc = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 4, F_, 32, 32, generator=gc).half().cuda()
+    ctx = torch.randn(1, 77, 768, generator=gc).half().cuda().expand(3, -1, -1).contiguous()
+    pipe = types.SimpleNamespace(unet=unet)
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    pnp_utils.register_time(pipe, 12)
+    got = unet(x, 741, encoder_hidden_states=ctx).sample
+    with torch.no_grad():
+        ref, _ = unet_ref.unet_forward(sd, cfg, x.float(), 741, ctx.float(), pnp_idx=12, exact_temporal=True)
+        plain, _ = unet_ref.unet_forward(sd, cfg, x.float(), 741, ctx.float(), pnp_idx=12, exact_temporal=False)
+    mx, rms = errs(got, ref)
+    record("trained_temporal_sd15_widths", dict(max_rel=mx, rms_rel=rms, temporal_effect_rms=errs(plain, ref)[1]))
+    assert torch.isfinite(got.float()).all()
+    assert mx < 5e-3 and rms < 3e-3, (mx, rms)
+    assert errs(plain, ref)[1] > 3e-2, "the perturbed temporal layers must matter"

@@ -50,6 +50,10 @@ struct UNet {
     bool finalized = false;
     int ln_fold = 1;          // transformer-block LayerNorms folded into the neighbouring linears: 0 none, 1 norm1 + norm2, 2 also norm3 (UNIVST_LN_FOLD)
     unsigned* d_counter = nullptr;
+    // TRAINED temporal layers (fine-tuned 3-D checkpoints): the units whose *_temporal* parameters differ from the identity
+    // initialisation (found on the device at finalize).  Empty for 2-D-initialised weights: the graph then skips them exactly.
+    std::unordered_map<std::string, int> temporal_conv_active;     // conv prefix ("...resnets.0.conv1", "conv_in", ...)
+    std::unordered_map<std::string, int> temporal_attn_active;     // transformer block prefix ("...transformer_blocks.0")
     std::string missing;
     // multi-GPU frame sharding hooks
     int rank = 0, world = 1;

@@ -112,6 +112,100 @@ __global__ void count_nonzero_kernel(const half_t* __restrict__ w, long n, unsig
     if (i < n && (float)w[i] != 0.f) atomicAdd(cnt, 1u);
 }
 
+// per-unit variants (slot i of a counter array): which temporal layers are trained?
+__global__ void count_not_dirac_slot_kernel(const half_t* __restrict__ w, int Co, int Ci, int k, unsigned* cnt) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Co * Ci * k) return;
+    int t = (int)(i % k), ci = (int)((i / k) % Ci), co = (int)(i / ((long)k * Ci));
+    float expect = (co == ci && t == k / 2) ? 1.f : 0.f;
+    if ((float)w[i] != expect) atomicAdd(cnt, 1u);
+}
+// Conv1d weight [C][C][3] over frames -> a 3x3 conv weight [C][ky][kx][CP] on the geometry (rows = frames, columns = pixels) whose
+// side columns (kx != 1) are zero: the temporal conv runs through the ordinary implicit-GEMM conv kernels
+__global__ void embed_temporal_weight_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int C) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)C * 9 * C) return;
+    const int ci = (int)(i % C), tap = (int)((i / C) % 9), co = (int)(i / ((long)C * 9));
+    const int ky = tap / 3, kx = tap % 3;
+    out[i] = kx == 1 ? in[((long)co * C + ci) * 3 + ky] : (half_t)0.f;
+}
+// trained temporal conv on few channels (conv_out: 4): y[b,f,p,co] = bias[co] + sum_t sum_ci W[co][ci][t] x[b,f+t-1,p,ci]
+__global__ void temporal_conv_small_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const half_t* __restrict__ w,
+                                           const half_t* __restrict__ bias, int B, int F, long HW, int C) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * F * HW * C) return;
+    const int co = (int)(i % C);
+    const long row = i / C;
+    const int f = (int)((row / HW) % F);
+    float acc = (float)bias[co];
+    for (int t = 0; t < 3; ++t) {
+        const int ff = f + t - 1;
+        if (ff < 0 || ff >= F) continue;
+        const half_t* xr = x + (row + (long)(t - 1) * HW) * C;
+        for (int ci = 0; ci < C; ++ci) acc += (float)w[((long)co * C + ci) * 3 + t] * (float)xr[ci];
+    }
+    y[i] = (half_t)acc;
+}
+// trained temporal attention (attention.py:336-346): every pixel attends over the F frames of its clip.  One thread per
+// (branch, pixel, head, query frame); q | k | v rows [(b f) n, 3C]; F <= 32.  A fine-tuned-checkpoint path: correctness first.
+template <int D8>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const half_t* __restrict__ qkv, half_t* __restrict__ out, int B, int F, int N, int C,
+                                                            int heads, float scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)B * N * heads * F) return;
+    const int n = (int)(i % N);
+    const int f = (int)((i / N) % F);
+    const int h = (int)((i / ((long)N * F)) % heads);
+    const int b = (int)(i / ((long)N * F * heads));
+    const long ld = 3L * C;
+    const half_t* base = qkv + ((long)b * F * N + n) * ld + h * (D8 * 8);      // frame 0 of this pixel
+    const long fs = (long)N * ld;                                             // frame stride
+    h8 q[D8];
+#pragma unroll
+    for (int c = 0; c < D8; ++c) q[c] = *reinterpret_cast<const h8*>(base + f * fs + c * 8);
+    float p[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+        p[g] = -INFINITY;
+        if (g < F) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < D8; ++c) {
+                const h8 k8 = *reinterpret_cast<const h8*>(base + g * fs + C + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += (float)q[c][e] * (float)k8[e];
+            }
+            p[g] = s * scale;
+            mx = fmaxf(mx, p[g]);
+        }
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+        p[g] = g < F ? __expf(p[g] - mx) : 0.f;
+        l += p[g];
+    }
+    const float inv = 1.f / l;
+    half_t* op = out + (((long)b * F + f) * N + n) * C + h * (D8 * 8);
+#pragma unroll 1
+    for (int c = 0; c < D8; ++c) {
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 32; ++g) {
+            if (g < F) {
+                const h8 v8 = *reinterpret_cast<const h8*>(base + g * fs + 2 * C + c * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += p[g] * (float)v8[e];
+            }
+        }
+        h8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (half_t)(o[e] * inv);
+        *reinterpret_cast<h8*>(op + c * 8) = r;
+    }
+}
+
 inline unsigned nb(long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -230,10 +324,28 @@ int UNet::derive_alloc(const std::string& k, std::vector<long> shape, half_t** o
 }
 
 int UNet::finalize(hipStream_t s) {
-    if (!d_counter) UV_HIP(hipMalloc(&d_counter, sizeof(unsigned)));
-    UV_HIP(hipMemsetAsync(d_counter, 0, sizeof(unsigned), s));
     std::vector<std::string> keys;
     for (auto& kv : weights) keys.push_back(kv.first);
+    // one counter per temporal UNIT (a conv's temporal weight + bias, a block's attn_temporal.to_out weight): non-zero = trained
+    std::vector<std::pair<std::string, int>> tunits;          // (prefix, 0 conv / 1 attention)
+    std::unordered_map<std::string, int> tslot;
+    for (const std::string& k : keys) {
+        size_t pos;
+        if ((pos = k.find(".conv_temporal.")) != std::string::npos) {
+            const std::string pre = k.substr(0, pos);
+            if (!tslot.count(pre)) { tslot[pre] = (int)tunits.size(); tunits.push_back({pre, 0}); }
+        } else if ((pos = k.find(".attn_temporal.to_out.0.weight")) != std::string::npos) {
+            const std::string pre = k.substr(0, pos);
+            if (!tslot.count(pre + "#a")) { tslot[pre + "#a"] = (int)tunits.size(); tunits.push_back({pre, 1}); }
+        }
+    }
+    const size_t ncnt = tunits.size() + 1;
+    if (d_counter) (void)hipFree(d_counter);
+    d_counter = nullptr;
+    UV_HIP(hipMalloc(&d_counter, ncnt * sizeof(unsigned)));
+    UV_HIP(hipMemsetAsync(d_counter, 0, ncnt * sizeof(unsigned), s));
+    temporal_conv_active.clear();
+    temporal_attn_active.clear();
     auto ends = [](const std::string& a, const char* suf) {
         size_t n = strlen(suf);
         return a.size() >= n && a.compare(a.size() - n, n, suf) == 0;
@@ -247,14 +359,18 @@ int UNet::finalize(hipStream_t s) {
     for (const std::string& k : keys) {
         const WTensor& t = weights[k];
         if (k.find("conv_temporal.weight") != std::string::npos) {
-            UV_REQUIRE(t.shape.size() == 3, "%s: expected [C,C,k]", k.c_str());
+            UV_REQUIRE(t.shape.size() == 3 && t.shape[0] == t.shape[1] && t.shape[2] == 3, "%s: expected a [C,C,3] Conv1d weight", k.c_str());
             long n = t.shape[0] * t.shape[1] * t.shape[2];
-            hipLaunchKernelGGL(count_not_dirac_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, (int)t.shape[0], (int)t.shape[1],
-                               (int)t.shape[2], d_counter);
-        } else if (k.find("conv_temporal.bias") != std::string::npos || ends(k, "attn_temporal.to_out.0.weight")) {
+            hipLaunchKernelGGL(count_not_dirac_slot_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, (int)t.shape[0], (int)t.shape[1],
+                               (int)t.shape[2], d_counter + tslot[k.substr(0, k.find(".conv_temporal."))]);
+        } else if (k.find("conv_temporal.bias") != std::string::npos) {
+            long n = t.shape[0];
+            hipLaunchKernelGGL(count_nonzero_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, n, d_counter + tslot[k.substr(0, k.find(".conv_temporal."))]);
+        } else if (ends(k, "attn_temporal.to_out.0.weight")) {
             long n = 1;
             for (long v : t.shape) n *= v;
-            hipLaunchKernelGGL(count_nonzero_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, n, d_counter);
+            hipLaunchKernelGGL(count_nonzero_kernel, dim3(nb(n)), dim3(256), 0, s, t.ptr, n,
+                               d_counter + tslot[k.substr(0, k.find(".attn_temporal.to_out.0.weight")) + "#a"]);
         } else if (t.shape.size() == 4 && k.find("_temporal") == std::string::npos) {
             // conv weights -> [Co][taps][CiP]
             int Co = (int)t.shape[0], Ci = (int)t.shape[1], taps = (int)(t.shape[2] * t.shape[3]);
@@ -377,14 +493,41 @@ int UNet::finalize(hipStream_t s) {
         }
     }
     UV_LAUNCH_CHECK();
-    unsigned bad = 0;
-    UV_HIP(hipMemcpyAsync(&bad, d_counter, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    std::vector<unsigned> hc(ncnt, 0);
+    UV_HIP(hipMemcpyAsync(hc.data(), d_counter, ncnt * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     UV_HIP(hipStreamSynchronize(s));
-    if (bad) {
-        uv_set_error("finalize: %u *_temporal* weights differ from the identity initialisation (dirac conv1d / zero "
-                     "attn_temporal.to_out); trained temporal layers are not supported by this build", bad);
-        return UV_ERR_UNSUPPORTED;
+    // trained temporal layers: derived layouts for the units that need them (resnet.py:70-80, attention.py:336-346)
+    for (size_t i = 0; i < tunits.size(); ++i) {
+        if (!hc[i]) continue;
+        const std::string& pre = tunits[i].first;
+        if (tunits[i].second == 0) {
+            const WTensor* w = find(pre + ".conv_temporal.weight");
+            UV_REQUIRE(w && find(pre + ".conv_temporal.bias"), "%s: conv_temporal weight / bias incomplete", pre.c_str());
+            const int C = (int)w->shape[0];
+            if (C % 8 == 0) {
+                half_t* d;
+                int rc = derive_alloc(pre + ".conv_temporal.weight#t3x3", {C, 9, C}, &d);
+                if (rc) return rc;
+                hipLaunchKernelGGL(embed_temporal_weight_kernel, dim3(nb((long)C * 9 * C)), dim3(256), 0, s, w->ptr, d, C);
+            }
+            temporal_conv_active[pre] = 1;
+        } else {
+            const WTensor *tq = find(pre + ".attn_temporal.to_q.weight"), *tk = find(pre + ".attn_temporal.to_k.weight"),
+                          *tv = find(pre + ".attn_temporal.to_v.weight");
+            UV_REQUIRE(tq && tk && tv && find(pre + ".norm_temporal.weight") && find(pre + ".norm_temporal.bias") &&
+                       find(pre + ".attn_temporal.to_out.0.bias"), "%s: attn_temporal / norm_temporal parameters incomplete", pre.c_str());
+            const long C = tq->shape[0], K = tq->shape[1];
+            half_t* d;
+            int rc = derive_alloc(pre + ".attn_temporal.qkv#fused", {3 * C, K}, &d);
+            if (rc) return rc;
+            UV_HIP(hipMemcpyAsync(d, tq->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            UV_HIP(hipMemcpyAsync(d + C * K, tk->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            UV_HIP(hipMemcpyAsync(d + 2 * C * K, tv->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
+            temporal_attn_active[pre] = 1;
+        }
     }
+    UV_LAUNCH_CHECK();
+    UV_HIP(hipStreamSynchronize(s));
     finalized = true;
     return UV_OK;
 }
@@ -532,7 +675,51 @@ struct Fwd {
         if (!g.W || !g.bias) return u.missing_error();
         g.partial = sk_ws;
         g.partial_bytes = UV_SPLITK_WS_BYTES;
-        return uv_launch_gemm(g, 1, s);
+        if (taps != 9 || !u.temporal_conv_active.count(p)) return uv_launch_gemm(g, 1, s);
+        // TRAINED temporal conv (resnet.py:70-80): spatial conv (+ its bias) -> Conv1d over the frames of every pixel -> whatever the
+        // caller wanted fused behind the PseudoConv3d (time-embedding row bias, residual).  The Conv1d runs as a 3x3 conv on the
+        // geometry (image rows = frames, image columns = pixels) with zero side taps (embed_temporal_weight_kernel).
+        half_t* mid = alloc(out->rows() * Cout);
+        if (!mid) return UV_ERR_STATE;
+        g.Y = mid;
+        g.rowbias = nullptr;
+        g.R = nullptr;
+        RUN(uv_launch_gemm(g, 1, s));
+        half_t *tw = W(p + ".conv_temporal.weight"), *tb = W(p + ".conv_temporal.bias");
+        if (!tw || !tb) return u.missing_error();
+        const long HWo = (long)g.Ho * g.Wo;
+        if (Cout % 8 != 0) {
+            UV_REQUIRE(!rowbias && !R, "%s: temporal conv on %d channels cannot carry a fused epilogue", p.c_str(), Cout);
+            hipLaunchKernelGGL(temporal_conv_small_kernel, dim3(nb(out->rows() * Cout)), dim3(256), 0, s, mid, out->p, tw, tb, B, F, HWo, Cout);
+            UV_LAUNCH_CHECK();
+        } else {
+            GemmParams t;
+            t.X = mid;
+            t.C1 = Cout;
+            t.Hs = F;
+            t.Ws = (int)HWo;
+            t.taps = 9;
+            t.Ho = F;
+            t.Wo = (int)HWo;
+            t.M = (int)out->rows();
+            t.N = Cout;
+            t.K = 9 * Cout;
+            t.W = W(p + ".conv_temporal.weight#t3x3");
+            t.bias = tb;
+            t.rowbias = rowbias;
+            t.ldrb = ldrb;
+            t.rows_per_rb = (int)(F * HWo);
+            t.R = R;
+            t.ldr = Cout;
+            t.Y = out->p;
+            t.ldy = Cout;
+            if (!t.W) return u.missing_error();
+            t.partial = sk_ws;
+            t.partial_bytes = UV_SPLITK_WS_BYTES;
+            RUN(uv_launch_gemm(t, 1, s));
+        }
+        free(mid);
+        return UV_OK;
     }
     // stats_out: emit the per-row (sum, sumsq) of Y for a following folded LayerNorm.  ln_in: fold LayerNorm(X) (statistics in ln_in,
     // ln_slots = K / 160 slots per row) into this linear: `wkey` then names the derived "#ln" weight and the bias comes with it.
@@ -724,9 +911,38 @@ struct Fwd {
         if (!tb) return u.missing_error();
         half_t* h4 = alloc(rows * C);
         if (!h4) return UV_ERR_STATE;
-        RUN(linear(mid, 4 * C, rows, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", C, h4, C, h3, C, tb));
+        const bool t_attn = u.temporal_attn_active.count(b) != 0;
+        RUN(linear(mid, 4 * C, rows, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", C, h4, C, h3, C, t_attn ? nullptr : tb));
         free(mid);
         free(h3);
+        if (t_attn) {      // TRAINED temporal attention (attention.py:336-346): LayerNorm, q|k|v, softmax over the F frames of every pixel, to_out + residual
+            UV_REQUIRE(F <= 32, "temporal attention: clips of %d frames (kernel holds <= 32 scores per query)", F);
+            gm = W(b + ".norm_temporal.weight"); bt = W(b + ".norm_temporal.bias");
+            if (!gm || !bt) return u.missing_error();
+            RUN(uv_launch_layernorm(h4, C, t0, C, gm, bt, rows, C, 1e-5f, s));
+            half_t* qkvt = alloc(rows * 3 * C);
+            if (!qkvt) return UV_ERR_STATE;
+            RUN(linear(t0, C, rows, C, b + ".attn_temporal.qkv#fused", "", 3 * C, qkvt, 3 * C));
+            const long nthr = (long)B * N * heads * F;
+            const float sc = 1.f / sqrtf((float)d);
+            switch (d) {
+                case 8: hipLaunchKernelGGL((temporal_attn_kernel<1>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                case 16: hipLaunchKernelGGL((temporal_attn_kernel<2>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                case 32: hipLaunchKernelGGL((temporal_attn_kernel<4>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                case 40: hipLaunchKernelGGL((temporal_attn_kernel<5>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                case 64: hipLaunchKernelGGL((temporal_attn_kernel<8>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                case 80: hipLaunchKernelGGL((temporal_attn_kernel<10>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                case 160: hipLaunchKernelGGL((temporal_attn_kernel<20>), dim3(nb(nthr)), dim3(256), 0, s, qkvt, t0, B, F, N, C, heads, sc); break;
+                default: uv_set_error("temporal attention: head_dim=%d not instantiated", d); return UV_ERR_UNSUPPORTED;
+            }
+            UV_LAUNCH_CHECK();
+            free(qkvt);
+            half_t* h5 = alloc(rows * C);
+            if (!h5) return UV_ERR_STATE;
+            RUN(linear(t0, C, rows, C, b + ".attn_temporal.to_out.0.weight", b + ".attn_temporal.to_out.0.bias", C, h5, C, h4, C));
+            free(h4);
+            h4 = h5;
+        }
         free(t0);
         out->imgs = x.imgs; out->H = x.H; out->W = x.W; out->C = C;
         out->p = alloc(rows * C);
@@ -746,6 +962,8 @@ int UNet::missing_error() {
 int UNet::forward(const half_t* sample, float timestep, const half_t* text, int B, int F, int H, int Wd, int text_len,
                   const univst_pnp_t* pnp, half_t* eps_out, half_t* feat_out, int ft_index, hipStream_t s) {
     UV_REQUIRE(finalized, "forward: call univst_unet_finalize after loading weights");
+    UV_REQUIRE(world == 1 || (temporal_conv_active.empty() && temporal_attn_active.empty()),
+               "forward: trained temporal layers couple all frames of a pixel; frame sharding (world=%d) is not supported with them", world);
     if (native_comm) {
         RUN(uv_comm_poll(native_comm));          // a peer timed out in an earlier call: report instead of queueing more work
         uv_comm_bind_stream(native_comm, s);
