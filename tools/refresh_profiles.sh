@@ -5,7 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-2}
+ROUND=${ROUND:-3}
 O=$R/gpurun_out/profiles_new
 rm -rf $O && mkdir -p $O/raw
 cd $R
@@ -21,6 +21,10 @@ python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROU
 python bench.py --frames 32 --emulate-rank 7/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank7of8.json 2>> $O/raw/bench.err
 python bench.py --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --no-cpu-baseline --no-skip-dead-branches-leg > $O/round${ROUND}_bench_f32_n1.json 2>> $O/raw/bench.err
+python bench.py --model sd21 --no-cpu-baseline > $O/round${ROUND}_bench_sd21_n1.json 2>> $O/raw/bench.err
+[ "${FULLCPU:-1}" = 1 ] && python bench.py --full-cpu --no-profile --no-skip-dead-branches-leg > $O/round${ROUND}_bench_fullcpu.json 2>> $O/raw/bench.err
+tools/probes/coissue_probe > $O/round${ROUND}_coissue_probe.txt 2>&1
+tools/probes/ipc_probe 1 > $O/round${ROUND}_ipc_probe.txt 2>&1
 ROUND=$ROUND python tools/summarize_profiles.py $O
 rm -rf $O/raw/stats/*/*_agent_info.csv
 ls -la $O
