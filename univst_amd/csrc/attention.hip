@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // front of the tile's barrier, a whole tile after the issue.  Rows past Nkv read a device zero page.
 __device__ __attribute__((aligned(256))) half_t uv_attn_zero_page[128];
 
-template <bool FOLD, int TAG = 0, int STG = 0>
+template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true>
 __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     constexpr int NW = 4;
     constexpr int D = 40, DV16 = 3, QB = 4, NST = 3;
@@ -640,7 +640,13 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     };
     // reference update for the scores `sc` of the NEXT step (deferred, T13).  Everything exponentiated so far is already in
     // O^T (the PV of the previous step precedes this in program order), so O^T is rescaled exactly once per change.
+    // ONEB: one wave-wide test over the four query blocks in front of the per-block tests (the common case — no reference moves —
+    // then costs 1 max3 + 1 max + 1 compare + 1 branch instead of 4 compares + 4 branches: +1.2 % in four same-box A/B pairs)
     auto decide = [&](f4 (&sc)[2][QB], const float (&mx)[QB], float lw, bool first) {
+        if (FOLD && ONEB && !first) {
+            const float mall = fmaxf(max3f(mx[0], mx[1], mx[2]), mx[3]);
+            if (__builtin_amdgcn_ballot_w64(mall > DEFER) == 0) return;
+        }
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             if (FOLD) {
@@ -1019,6 +1025,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
             // UNIVST_ATTN_STG (A/B aid): 1 = K/V ring filled by LDS-DMA (default), 0 = through registers
             static const int stg = getenv("UNIVST_ATTN_STG") ? atoi(getenv("UNIVST_ATTN_STG")) : 1;
             if (pp == 2 && text) hipLaunchKernelGGL((attn_pp40_kernel<true, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else if (pp == 2 && stg == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);      // A/B: four per-block tests
             else if (pp == 2 && stg) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_pp40_kernel<false, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
