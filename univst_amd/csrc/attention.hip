@@ -379,8 +379,9 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // front of the tile's barrier, a whole tile after the issue.  Rows past Nkv read a device zero page.
 __device__ __attribute__((aligned(256))) half_t uv_attn_zero_page[128];
 
-template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true>
+template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true, bool K16 = false>
 __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
+    static_assert(!K16 || FOLD, "the 16-wide second k step carries the folded reference columns");
     constexpr int NW = 4;
     constexpr int D = 40, DV16 = 3, QB = 4, NST = 3;
     constexpr int KSTR = lds_stride_bytes(64 * 2) / 2;       // 80 halfs
@@ -420,7 +421,18 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
             h8 v = (qrow < p.Nq && dc < D) ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + dc) : zero8;
             qf[qb][ks] = v;
         }
-        if (FOLD && g == 1) qf[qb][1][2] = (half_t)lw_cur;        // column 42: + log2 multiplicity of the source
+        if (FOLD && !K16 && g == 1) qf[qb][1][2] = (half_t)lw_cur;        // column 42: + log2 multiplicity of the source
+        if (K16) {
+            // K16: the second k step covers columns 32..47 only (head_dim 40 + the three folded-reference columns) on the 16-wide
+            // MFMA: lane (q, g) holds columns 32 + 4g .. +3 in the LOW half of qf[qb][1] — g 0/1: q[32..39], g 2: (-M_hi, -M_lo, lw, 0)
+            h8 v = zero8;
+            if (qrow < p.Nq && g < 2) {
+                const h4 t = *reinterpret_cast<const h4*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + 32 + g * 4);
+                v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+            }
+            if (g == 2) v[2] = (half_t)lw_cur;
+            qf[qb][1] = v;
+        }
     }
     // columns 40 / 41 of Q' <- -M (FOLD).  Returns the reference the MFMA will REALLY subtract: -(fp16(-hi) + fp16(-lo)), equal
     // to M whenever |M| < 16384 (hi a multiple of 8, lo a multiple of 1/64 below 8 are exact in fp16); beyond that the
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     auto set_shift = [&](int qb, float M) -> float {
         const float hi = floorf(M * 0.125f) * 8.f, lo = M - hi;
         const half_t hh = (half_t)(-hi), lh = (half_t)(-lo);
-        if (g == 1) {
+        if (g == (K16 ? 2 : 1)) {
             qf[qb][1][0] = hh;
             qf[qb][1][1] = lh;
         }
@@ -568,8 +580,18 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (STG ? (hh * 32 + kb * 16) * 8 + ks * 4 * KPL : (hh * 32 + kb * 16) * KSTR + ks * 32)]);
+            for (int ks = 0; ks < 2; ++ks) {
+                if (K16 && ks == 1) {       // columns 32 + 4g .. +3 of the key row: 8 bytes per lane
+                    const int o16 = STG ? (4 + (g >> 1)) * KPL + l15 * 8 + (g & 1) * 4 + (hh * 32 + kb * 16) * 8
+                                        : l15 * KSTR + 32 + g * 4 + (hh * 32 + kb * 16) * KSTR;
+                    const h4 t = *reinterpret_cast<const h4*>(&st[o16]);
+                    h8 v = zero8;
+                    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+                    kf[kb][1] = v;
+                } else {
+                    kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (STG ? (hh * 32 + kb * 16) * 8 + ks * 4 * KPL : (hh * 32 + kb * 16) * KSTR + ks * 32)]);
+                }
+            }
     };
     auto vfrag_read = [&](const half_t* st, int hh, h8 (&vf)[DV16]) {
 #pragma unroll
@@ -583,8 +605,22 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
             vf[dv] = a;
         }
     };
+    auto lo4 = [](const h8& v) { h4 r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; return r; };
     auto qk = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {        // S^T of one 32-key step: 16 MFMAs
         const f4 z = {0.f, 0.f, 0.f, 0.f};
+        if (K16) {
+            // the 16-wide step FIRST, from zero (half the matrix time of a 32-wide one), then the 32-wide step accumulates on it: each
+            // dependent pair is 8 independent MFMAs apart, far beyond any wait state the two opcode families need between them
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(kf[kb][1]), lo4(qf[qb][1]), z, 0, 0, 0);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], sc[kb][qb], 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -693,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         }
     };
     auto set_lw = [&](float lw) {                                  // FOLD: column 42 of Q' <- log2 multiplicity of the source
-        if (g == 1) {
+        if (g == (K16 ? 2 : 1)) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) qf[qb][1][2] = (half_t)lw;
         }
@@ -1022,11 +1058,13 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         if (!p.kx && p.Nq >= 2048 && ((pp == 2 && p.q_prescaled) || pp == 1)) {
             const int nqb4 = (p.Nq + 255) / 256;
             const bool text = p.nsrc == 1 && p.Nkv <= 128;
-            // UNIVST_ATTN_STG (A/B aid): 1 = K/V ring filled by LDS-DMA (default), 0 = through registers
+            // UNIVST_ATTN_STG (A/B aid): 1 (default) = K/V ring filled by LDS-DMA + one wave-wide reference test + 16-wide second k step;
+            // 2 = the same with four per-block tests, 3 = with the 32-wide second k step; 0 = the round-2 kernel (ring through registers)
             static const int stg = getenv("UNIVST_ATTN_STG") ? atoi(getenv("UNIVST_ATTN_STG")) : 1;
             if (pp == 2 && text) hipLaunchKernelGGL((attn_pp40_kernel<true, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
-            else if (pp == 2 && stg == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);      // A/B: four per-block tests
-            else if (pp == 2 && stg) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else if (pp == 2 && stg == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, false, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else if (pp == 2 && stg == 3) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            else if (pp == 2 && stg) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_pp40_kernel<false, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
