@@ -61,3 +61,46 @@ def test_async_load_destinations_untouched_until_wait(tmp_path):
     assert nloads >= 8, "no asm prefetch loads found: the check is not looking at the right code"
     kernels = sorted({q.split(":")[0] for q in problems})
     assert not problems, f"{len(problems)} hazards in {kernels}\n" + "\n".join(problems[:10])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_mixed_mfma_families_are_fenced(tmp_path):
+    """hipcc (ROCm 7.2) does not pad the dependency  v_mfma_f32_16x16x16_f16 D  ->  v_mfma_f32_16x16x32_f16 SrcC = D  with enough wait
+    states: issued back to back the 32-wide MFMA reads stale accumulator registers (met in attn_text_kernel in round 2, and again in
+    round 3 when an interleave hint let the scheduler pair the two in attn_pp40_kernel's 16-wide second k step: wrong scores, no
+    fault) — and it is the scheduler, not the source order, that decides how close the two end up (it moved MFMAs across
+    sched_barrier(0) by sinking them at IR level).  The kernel therefore puts a data-flow fence between the two families: an empty
+    asm that READS every 16-wide result (hipcc does pad MFMA result -> VGPR read) and redefines an operand of every 32-wide MFMA.
+    This test reads the ISA: between a 16-wide MFMA and any 32-wide MFMA that accumulates on its result there must be an
+    ;;#ASMSTART marker."""
+    asm = tmp_path / "attention.s"
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", f"-I{ROOT}/include", "-S", "--cuda-device-only",
+                    f"{ROOT}/univst_amd/csrc/attention.hip", "-o", str(asm)], check=True, capture_output=True, timeout=900)
+    kernel, n_asm, writers, pairs, problems = None, 0, {}, 0, []
+    for line in asm.read_text().splitlines():
+        s = line.strip()
+        if s.startswith("_Z") and ":" in s.split(";")[0]:
+            kernel, n_asm, writers = s.split(":")[0], 0, {}
+            continue
+        if s.startswith(";;#ASMSTART"):
+            n_asm += 1
+            continue
+        body = s.split(";")[0]
+        if not body.startswith("v_mfma_f32_16x16x"):
+            continue
+        ops = [o.strip() for o in body.split(None, 1)[1].split(",")]
+        dst = regs(ops[0])
+        if body.startswith("v_mfma_f32_16x16x16_f16"):
+            for r in dst:
+                writers[r] = n_asm
+        elif body.startswith("v_mfma_f32_16x16x32_f16"):
+            srcc = regs(ops[3]) if len(ops) > 3 else set()
+            hit = [writers[r] for r in srcc if r in writers]
+            if hit:
+                pairs += 1
+                if n_asm == max(hit):
+                    problems.append(f"{kernel}: `{body}` accumulates on a 16-wide MFMA result with no fence in between")
+            for r in dst:
+                writers.pop(r, None)
+    assert pairs >= 8, "no 16-wide -> 32-wide accumulator hand-over found: the check is not looking at the kernel it is meant for"
+    assert not problems, "\n".join(problems[:10])

@@ -606,19 +606,40 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         }
     };
     auto lo4 = [](const h8& v) { h4 r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; return r; };
+    // K16: the 16-wide step FIRST, from zero (half the matrix time of a 32-wide one), then the 32-wide step accumulates on it.
+    // hipcc (ROCm 7.2) leaves too few wait states when a v_mfma_f32_16x16x32_f16 takes the result of a v_mfma_f32_16x16x16_f16 as
+    // SrcC right behind it — the same toolchain hazard attn_text_kernel met, and it is its scheduler, not the source order, that decides
+    // how close the two end up (a variant whose interleave hints let it pair them back to back returned wrong scores).  The two
+    // two families are therefore separated by a data-flow fence (qk_fence) at every call site, and sit in separate scheduling regions:
+    // whatever the scheduler does, a 32-wide MFMA reads an accumulator that the 16-wide one has finished writing
+    // (tests/test_asm_hazards.py checks in the ISA that every such pair has the fence between them).
+    auto qk_a = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(kf[kb][1]), lo4(qf[qb][1]), z, 0, 0, 0);
+    };
+    // the fence between the two families: an empty asm that READS all eight 16-wide results and redefines the B operands of the
+    // 32-wide MFMAs.  Every 16-wide MFMA must issue — and, because hipcc pads an MFMA result -> VGPR read correctly, must have WRITTEN
+    // its result — before it; every 32-wide MFMA needs an operand defined by it and issues after it.
+    auto qk_fence = [&](f4 (&sc)[2][QB]) {
+        asm volatile("" : "+v"(qf[0][0]), "+v"(qf[1][0]), "+v"(qf[2][0]), "+v"(qf[3][0])
+                     : "v"(sc[0][0]), "v"(sc[0][1]), "v"(sc[0][2]), "v"(sc[0][3]), "v"(sc[1][0]), "v"(sc[1][1]), "v"(sc[1][2]), "v"(sc[1][3]));
+    };
+    auto qk_b = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], sc[kb][qb], 0, 0, 0);
+    };
     auto qk = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {        // S^T of one 32-key step: 16 MFMAs
         const f4 z = {0.f, 0.f, 0.f, 0.f};
-        if (K16) {
-            // the 16-wide step FIRST, from zero (half the matrix time of a 32-wide one), then the 32-wide step accumulates on it: each
-            // dependent pair is 8 independent MFMAs apart, far beyond any wait state the two opcode families need between them
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x16f16(lo4(kf[kb][1]), lo4(qf[qb][1]), z, 0, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], sc[kb][qb], 0, 0, 0);
+        if (K16) {          // (prologue only: the loop interleaves the two halves with the softmax of the previous step)
+            qk_a(kf, sc);
+            qk_fence(sc);
+            __builtin_amdgcn_sched_barrier(0);
+            qk_b(kf, sc);
             return;
         }
 #pragma unroll
@@ -644,6 +665,21 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
                     e0 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][0], c, mc[qb])); e1 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][1], c, mc[qb]));
                     e2 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][2], c, mc[qb])); e3 = __builtin_amdgcn_exp2f(fmaf(sc[kb][qb][3], c, mc[qb]));
                 }
+                u.h[kb * 2] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+                u.h[kb * 2 + 1] = __builtin_amdgcn_cvt_pkrtz(e2, e3);
+            }
+            pb[qb] = u.v;
+        }
+    };
+    auto exp_half = [&](const f4 (&sc)[2][QB], h8 (&pb)[QB], int half) {      // query blocks 2*half, 2*half + 1 (FOLD arithmetic)
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            const int qb = half * 2 + q2;
+            union { fh2 h[4]; h8 v; } u;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const float e0 = __builtin_amdgcn_exp2f(sc[kb][qb][0]), e1 = __builtin_amdgcn_exp2f(sc[kb][qb][1]);
+                const float e2 = __builtin_amdgcn_exp2f(sc[kb][qb][2]), e3 = __builtin_amdgcn_exp2f(sc[kb][qb][3]);
                 u.h[kb * 2] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
                 u.h[kb * 2 + 1] = __builtin_amdgcn_cvt_pkrtz(e2, e3);
             }
@@ -743,6 +779,14 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                        \
         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        \
     }
+/* K16: a step's scores come in two scheduling regions (8 MFMAs each), each with half of the previous step's exponentials */ \
+#define UV_PP_PHASE1H(DS)                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        if ((DS) && i_ < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    \
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        \
+    }
 #define UV_PP_PHASE2()                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                           \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
@@ -753,6 +797,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 // an empty asm that "uses" four values: keeps their producers in this basic block (LLVM otherwise sinks the exp2 / max
 // work below the next branch, out of reach of the interleave above)
 #define UV_PP_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define UV_PP_PIN2(a, i) asm volatile("" : "+v"(a[i]), "+v"(a[(i) + 1]))
 
     // ---- prologue: tiles 0 and 1 into the ring, scores + reference of step (0, 0)
     if (STG) {
@@ -795,10 +840,23 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         }
         // ---- step (tt, 0): scores of (tt, 1) on the matrix pipe while (tt, 0) is exponentiated
         vfrag_read(b_cur, 0, vf);
-        qk(kf, scB);
-        exp_part(scA, pb);
-        UV_PP_PIN4(pb);
-        UV_PP_PHASE1();
+        if (K16) {
+            qk_a(kf, scB);
+            exp_half(scA, pb, 0);
+            UV_PP_PIN2(pb, 0);
+            UV_PP_PHASE1H(1);
+            qk_fence(scB);
+            __builtin_amdgcn_sched_barrier(0);
+            qk_b(kf, scB);
+            exp_half(scA, pb, 1);
+            UV_PP_PIN2(pb, 2);
+            UV_PP_PHASE1H(0);
+        } else {
+            qk(kf, scB);
+            exp_part(scA, pb);
+            UV_PP_PIN4(pb);
+            UV_PP_PHASE1();
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (t0_cur + KT > p.Nkv) mask_tail(scB, t0_cur + 32);
         kfrag_read(b_nxt, 0, kf);
@@ -811,10 +869,23 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         // ---- step (tt, 1): scores of (tt+1, 0)
         if (FOLD && lw_nxt != lw_cur) set_lw(lw_nxt);
         vfrag_read(b_cur, 1, vf);
-        qk(kf, scA);
-        exp_part(scB, pb);
-        UV_PP_PIN4(pb);
-        UV_PP_PHASE1();
+        if (K16) {
+            qk_a(kf, scA);
+            exp_half(scB, pb, 0);
+            UV_PP_PIN2(pb, 0);
+            UV_PP_PHASE1H(1);
+            qk_fence(scA);
+            __builtin_amdgcn_sched_barrier(0);
+            qk_b(kf, scA);
+            exp_half(scB, pb, 1);
+            UV_PP_PIN2(pb, 2);
+            UV_PP_PHASE1H(0);
+        } else {
+            qk(kf, scA);
+            exp_part(scB, pb);
+            UV_PP_PIN4(pb);
+            UV_PP_PHASE1();
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (has_next && t0_nxt + KT > p.Nkv) mask_tail(scA, t0_nxt);
         kfrag_read(b_nxt, 1, kf);
@@ -838,6 +909,8 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         t0_nxt = nx_t * KT;
     }
 #undef UV_PP_PHASE1
+#undef UV_PP_PHASE1H
+#undef UV_PP_PIN2
 #undef UV_PP_PIN4
 #undef UV_PP_PHASE2
 
