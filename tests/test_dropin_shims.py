@@ -62,3 +62,43 @@ def test_cli_scripts_keep_the_reference_flags(script):
                                             "--weight_dtype", "--time_steps", "--seed"]}[script]
     for flag in want:
         assert flag in out.stdout, f"{script}: flag {flag} missing from --help"
+
+
+def test_mp4_content_input_goes_through_decord(monkeypatch, tmp_path):
+    """ddim_inversion.py:21-27: VideoReader(path, width=, height=), first num_frames frames, /127.5 - 1, (b f) c h w.  decord is not in
+    this image, so a stand-in module records the calls; without it the branch raises ImportError naming decord."""
+    import sys
+    import types
+    import numpy as np
+    import torch
+    from univst_amd.inversion_tools import ddim_inversion as di
+
+    monkeypatch.setitem(sys.modules, "decord", None)
+    import pytest
+    with pytest.raises(ImportError, match="decord"):
+        di.read_content_pixels(str(tmp_path / "clip.mp4"), 4, 32, 48)
+
+    calls = {}
+    rng = np.random.default_rng(0)
+    frames = torch.from_numpy(rng.integers(0, 256, (9, 32, 48, 3), dtype=np.uint8))
+
+    class Reader:
+        def __init__(self, path, width=None, height=None):
+            calls["open"] = (path, width, height)
+
+        def __len__(self):
+            return frames.shape[0]
+
+        def get_batch(self, idx):
+            calls["idx"] = list(idx)
+            return frames[idx]
+
+    fake = types.ModuleType("decord")
+    fake.VideoReader = Reader
+    fake.bridge = types.SimpleNamespace(set_bridge=lambda name: calls.setdefault("bridge", name))
+    monkeypatch.setitem(sys.modules, "decord", fake)
+    px = di.read_content_pixels(str(tmp_path / "clip.mp4"), 4, 32, 48)
+    assert calls == {"bridge": "torch", "open": (str(tmp_path / "clip.mp4"), 48, 32), "idx": [0, 1, 2, 3]}
+    assert px.shape == (4, 3, 32, 48) and px.dtype == torch.float32
+    want = (frames[:4].float() / 127.5 - 1.0).permute(0, 3, 1, 2)
+    assert torch.equal(px, want)

@@ -14,13 +14,28 @@ def _encode_frames(pipe, pixel_values, num_frames):
     return latents * pipe.vae.config.scaling_factor
 
 
+def read_content_pixels(content_path, num_frames, height, width):
+    """[F, 3, H, W] float in [-1, 1] on the CPU.  ddim_inversion.py:21-27: an .mp4 goes through decord.VideoReader(width, height) and
+    keeps the first num_frames frames; anything else is a frame folder (src/util.py load_video_frames).  decord is imported here,
+    on first use, not at module import as the reference does (ddim_inversion.py:12-13): PNG-folder users do not need it."""
+    if content_path.endswith(".mp4"):
+        try:
+            import decord
+        except ImportError as e:
+            raise ImportError(".mp4 content input is read with decord (as in the reference); install it or extract the frames to "
+                              "a folder of %05d.png files") from e
+        decord.bridge.set_bridge("torch")
+        vr = decord.VideoReader(content_path, width=width, height=height)
+        video = vr.get_batch(list(range(0, len(vr), 1))[:num_frames])          # [F, H, W, 3] uint8
+        return (torch.as_tensor(video).float() / 127.5 - 1.0).permute(0, 3, 1, 2).contiguous()
+    return load_video_frames(content_path, num_frames, image_size=(width, height))
+
+
 def content_inversion_reconstruction(pipe, ddim_inv_scheduler, content_path, inversion_path, reconstruction_path, num_frames,
                                      height, width, time_steps, weight_dtype, ft_indices=None, ft_timesteps=None, ft_path=None,
                                      is_opt=True, reconstruct=True):
-    """ddim_inversion.py:16-42 (PNG-folder input; .mp4 needs decord which is not part of this build)."""
-    if content_path.endswith(".mp4"):
-        raise NotImplementedError(".mp4 input needs decord; extract frames to %05d.png")
-    pixel_values = load_video_frames(content_path, num_frames, image_size=(width, height)).to(weight_dtype).cuda()
+    """ddim_inversion.py:16-42: a folder of %05d.png frames or an .mp4 (read with decord, the reference's reader)."""
+    pixel_values = read_content_pixels(content_path, num_frames, height, width).to(weight_dtype).cuda()
     latents = _encode_frames(pipe, pixel_values, num_frames)
     print("inversion:")
     z = ddim_inversion(pipe, ddim_inv_scheduler, video_latent=latents, num_inv_steps=time_steps, prompt="",
