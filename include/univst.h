@@ -172,6 +172,8 @@ int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, i
  * documented fixed reading thresh2 == eta2 — the reference reads an attribute it never sets).  hidden [B, N, Cin] image tokens of
  * B = (branches x clip_length) frames, enc [B, Nt, Cin] text tokens or NULL; keys of frame f = image tokens of ['first', f-1, f]
  * of its clip (read by pointer) ++ its text tokens (one extra key segment); out_img [B, N, Cin], out_txt [B, Nt, Cin].
+ * clip_length == 0: no cross-frame gather — keys of frame f are its own image tokens ++ its text tokens (diffusers' stock
+ * JointAttnProcessor2_0, what the MM-DiT runs before register_spatial_attention_pnp / with no processor set).
  * Weights are diffusers' Attention parameters, fp16 device pointers, [out, in] row-major; NULL = absent (biases, the RMS norms of
  * SD3-medium, to_add_out when context_pre_only). */
 typedef struct {
@@ -192,10 +194,28 @@ int univst_sd3_adain_shift(void* qkv, int64_t ld, int F, int N, int C, int heads
                            void* stream);
 /* diffusers RMSNorm over the head dim, in place: x[r, h*d + e] *= rsqrt(mean_e x^2 + eps) * weight[e]  (row stride ld) */
 int univst_rmsnorm_heads(void* x, int64_t ld, int64_t rows, int heads, int head_dim, const void* weight, float eps, void* stream);
-/* y = LayerNorm(x; no affine, eps) * (1 + scale[b]) + shift[b]: AdaLayerNormZero / Continuous of the MM-DiT blocks; x, y [rows, C],
- * scale / shift [rows / rows_per_batch, C] */
-int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t rows, int64_t rows_per_batch, int C,
-                          float eps, void* stream);
+/* y = LayerNorm(x; no affine, eps) * (1 + scale[b]) + shift[b]: AdaLayerNormZero / ZeroX / Continuous of the MM-DiT blocks (diffusers
+ * normalization.py, third-party).  x, y [rows, C] (C % 8 == 0, <= 4096); scale / shift are rows of a [rows / rows_per_batch, ...]
+ * matrix ld_mod halfs apart (chunks of the adaLN linear's output).  y2 / scale2 / shift2 (all NULL or all set): a second modulation
+ * of the same normalised rows (AdaLayerNormZeroX, the dual-attention blocks of SD3.5-medium). */
+int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t ld_mod, int64_t rows, int64_t rows_per_batch,
+                          int C, float eps, void* y2, const void* scale2, const void* shift2, void* stream);
+/* out = x + gate[b] * y: the gated residuals of diffusers' JointTransformerBlock (gate rows ld_gate halfs apart; out may alias x) */
+int univst_gate_residual(const void* x, const void* gate, int64_t ld_gate, const void* y, void* out, int64_t rows, int64_t rows_per_batch, int C,
+                         void* stream);
+/* elementwise activation, fp32 arithmetic (n % 8 == 0; out may alias x): SiLU (adaLN / timestep / pooled-text MLPs) and GELU(tanh)
+ * (FeedForward activation_fn="gelu-approximate") */
+#define UNIVST_ACT_SILU 0
+#define UNIVST_ACT_GELU_TANH 1
+int univst_activation(const void* x, void* out, int64_t n, int act, void* stream);
+/* diffusers Timesteps / get_timestep_embedding: t fp32 [B] (device) -> out fp16 [B, dim] = [sin | cos](t * freq) (halves swapped when
+ * flip_sin_to_cos), freq_i = exp(-ln(max_period) i / (dim/2 - downscale_freq_shift)), fp32 arithmetic */
+int univst_timestep_embedding(const float* t, void* out, int B, int dim, int flip_sin_to_cos, float downscale_freq_shift, float max_period,
+                              void* stream);
+/* PatchEmbed's strided conv as a linear: latents [B, C, H, W] -> rows [B*(H/p)*(W/p), C*p*p] in the k order of the flattened conv
+ * weight; and the inverse for proj_out's rows [.., p*p*C] ((u, v, c) order) -> latents (transformer_3D_model.py:95-103) */
+int univst_sd3_patchify(const void* latents, void* rows, int B, int C, int H, int W, int patch, void* stream);
+int univst_sd3_unpatchify(const void* rows, void* latents, int B, int C, int H, int W, int patch, void* stream);
 /* out = a*x + b*y + c*z (fp16 storage, fp32 arithmetic): the updates of rf_inversion / rf_solver (flow_inversion.py:123-264) */
 int univst_axpbypcz(const void* x, const void* y, const void* z, void* out, float a, float b, float c, int64_t n, void* stream);
 

@@ -1,8 +1,8 @@
 """Oracle groundwork for SURVEY §8f-4 (SD3 / SD3.5 rectified-flow backbone): the REFERENCE-OWNED pieces of that path.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Nothing in univst_amd/ implements this path yet: this file and the goldens
-G15-G17 are the "oracle + goldens first" step the round-1 verdict prescribes for config 5, so that a HIP path built later has a
-pinned target.  Restated here (each function cites what it follows):
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  The HIP path it checks: csrc/sd3.hip behind
+univst_amd/backbones/video_diffusion_sd3/ and univst_amd/inversion_tools/flow_inversion.py.  Pinned to reference code by goldens
+G15-G18 (each function cites what it follows):
 
   * attention_adain / latent_adain of the SD3 plugin          backbones/video_diffusion_sd3/pnp_utils.py:287-316
   * the cross-frame key/value gather ['first', -1, 0]          pnp_utils.py:27,53-78
@@ -14,8 +14,10 @@ never set (pnp_utils.py:186).  The documented FIXED READING used here and by the
 value that makes beta run from 0.9 at eta1*50 to 0.1 at eta2*50, like the SD-v1.5 closure, pnp_utils.py:49-50 of that plugin);
 the generator sets that attribute on the processor instance before calling the reference's own __call__ — no reference code is
 edited or copied.  The MM-DiT backbone itself (diffusers SD3Transformer2DModel: patch embedding, adaLN, the joint transformer
-blocks around these processors) and the FlowMatchEuler sigma schedule are third-party and absent: parity unpinned for those.
+blocks around these processors) and the FlowMatchEuler sigma schedule are third-party and absent: the restatements at the end of
+this file (`joint_transformer_block`, `sd3_block`, `sd3_transformer`) are PARITY UNPINNED and say so.
 """
+import math
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -85,8 +87,9 @@ def joint_attention(P: Dict[str, torch.Tensor], heads: int, hidden: torch.Tensor
             k[2 * c:3 * c] = beta * attention_adain(k[2 * c:3 * c], k[c:2 * c]) + (1 - beta) * k[c:2 * c]
             v[2 * c:3 * c] = beta * attention_adain(v[2 * c:3 * c], v[c:2 * c]) + (1 - beta) * v[c:2 * c]
             q[2 * c:3 * c] = gamma * q[2 * c:3 * c]
-    k = cross_frame_gather(k, clip_length)
-    v = cross_frame_gather(v, clip_length)
+    if clip_length:                                        # 0: diffusers' stock JointAttnProcessor2_0 (no cross-frame keys)
+        k = cross_frame_gather(k, clip_length)
+        v = cross_frame_gather(v, clip_length)
     if enc is not None:
         eq, ek, ev = sp(lin(enc, "add_q_proj")), sp(lin(enc, "add_k_proj")), sp(lin(enc, "add_v_proj"))
         eq = _rms(eq, P.get("norm_added_q.weight"), rms_eps)
@@ -176,3 +179,91 @@ def joint_transformer_block(P: Dict[str, torch.Tensor], heads: int, hidden: torc
     n2c = F.layer_norm(enc, (enc.shape[-1],), None, None, 1e-6) * (1 + c_scale_mlp[:, None]) + c_shift_mlp[:, None]
     enc = enc + c_gate_mlp[:, None] * feed_forward_gelu_tanh(n2c, P, "ff_context")
     return enc, hidden
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# THIRD-PARTY, PARITY UNPINNED: the rest of diffusers 0.35.1 `SD3Transformer2DModel` (models/transformers/transformer_sd3.py) as the
+# reference's CustomSD3Transformer2DModel.forward drives it (transformer_3D_model.py:44-103): PatchEmbed with a centre-cropped
+# positional table, CombinedTimestepTextProjEmbeddings, the context embedder, the block stack incl. the dual-attention blocks of
+# SD3.5-medium (AdaLayerNormZeroX, attn2) and the context_pre_only last block (AdaLayerNormContinuous), norm_out, proj_out and the
+# unpatchify.  Restated from the published definitions; nothing in the reference tree or on either box can pin it.  P: the model's
+# state dict under diffusers' parameter names, fp32.
+def timestep_embedding(t: torch.Tensor, dim: int = 256, flip_sin_to_cos: bool = True, downscale_freq_shift: float = 0.0,
+                       max_period: float = 10000.0) -> torch.Tensor:
+    """embeddings.get_timestep_embedding (scale 1)."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / (half - downscale_freq_shift)
+    emb = t.float()[:, None] * torch.exp(exponent)[None]
+    emb = torch.cat([emb.sin(), emb.cos()], dim=-1)
+    return torch.cat([emb[:, half:], emb[:, :half]], dim=-1) if flip_sin_to_cos else emb
+
+
+def _lin(x, P, pre):
+    return F.linear(x, P[pre + ".weight"], P.get(pre + ".bias"))
+
+
+def _ln(x):
+    return F.layer_norm(x, (x.shape[-1],), None, None, 1e-6)
+
+
+def sd3_block(P: Dict[str, torch.Tensor], pre: str, heads: int, hidden, enc, temb, dual: bool, context_pre_only: bool,
+              attn_kw: Optional[dict] = None):
+    """JointTransformerBlock.forward incl. use_dual_attention / context_pre_only.  attn_kw: arguments of `joint_attention` above
+    (idx, shift, eta1, eta2, clip_length; clip_length 0 = diffusers' stock processor, no cross-frame keys)."""
+    kw = dict(attn_kw or {})
+    sub = lambda name: {k[len(pre + name + "."):]: v for k, v in P.items() if k.startswith(pre + name + ".")}   # noqa: E731
+    emb = _lin(F.silu(temb), P, pre + "norm1.linear")
+    if dual:
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m, sh_a2, sc_a2, g_a2 = emb.chunk(9, dim=1)
+    else:
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = emb.chunk(6, dim=1)
+    nx = _ln(hidden)
+    nh = nx * (1 + sc_a[:, None]) + sh_a[:, None]
+    cemb = _lin(F.silu(temb), P, pre + "norm1_context.linear")
+    if context_pre_only:
+        c_sc, c_sh = cemb.chunk(2, dim=1)                           # AdaLayerNormContinuous: scale first
+        ne = _ln(enc) * (1 + c_sc[:, None]) + c_sh[:, None]
+    else:
+        c_sh_a, c_sc_a, c_g_a, c_sh_m, c_sc_m, c_g_m = cemb.chunk(6, dim=1)
+        ne = _ln(enc) * (1 + c_sc_a[:, None]) + c_sh_a[:, None]
+    a_img, a_txt = joint_attention(sub("attn"), heads, nh, ne, context_pre_only=context_pre_only, **kw)
+    hidden = hidden + g_a[:, None] * a_img
+    if dual:
+        nh2 = nx * (1 + sc_a2[:, None]) + sh_a2[:, None]
+        hidden = hidden + g_a2[:, None] * joint_attention(sub("attn2"), heads, nh2, None, **kw)
+    n2 = _ln(hidden) * (1 + sc_m[:, None]) + sh_m[:, None]
+    hidden = hidden + g_m[:, None] * feed_forward_gelu_tanh(n2, P, pre + "ff")
+    if context_pre_only:
+        return None, hidden
+    enc = enc + c_g_a[:, None] * a_txt
+    n2c = _ln(enc) * (1 + c_sc_m[:, None]) + c_sh_m[:, None]
+    enc = enc + c_g_m[:, None] * feed_forward_gelu_tanh(n2c, P, pre + "ff_context")
+    return enc, hidden
+
+
+def sd3_transformer(P: Dict[str, torch.Tensor], cfg, latents, enc_in, pooled, timestep, attn_kw: Optional[dict] = None,
+                    features: Optional[dict] = None):
+    """CustomSD3Transformer2DModel.forward (transformer_3D_model.py:44-103).  cfg: patch_size, num_layers, num_attention_heads,
+    out_channels, pos_embed_max_size, dual_attention_layers.  features (optional dict): hidden states after each block."""
+    B, Cc, H, W = latents.shape
+    p = cfg.patch_size
+    hp, wp = H // p, W // p
+    x = F.conv2d(latents, P["pos_embed.proj.weight"], P["pos_embed.proj.bias"], stride=p).flatten(2).transpose(1, 2)
+    m = cfg.pos_embed_max_size
+    top, left = (m - hp) // 2, (m - wp) // 2
+    pos = P["pos_embed.pos_embed"].reshape(1, m, m, -1)[:, top:top + hp, left:left + wp].reshape(1, hp * wp, -1)
+    x = x + pos
+    t_emb = _lin(F.silu(_lin(timestep_embedding(timestep.reshape(-1).expand(B)), P, "time_text_embed.timestep_embedder.linear_1")), P,
+                 "time_text_embed.timestep_embedder.linear_2")
+    p_emb = _lin(F.silu(_lin(pooled, P, "time_text_embed.text_embedder.linear_1")), P, "time_text_embed.text_embedder.linear_2")
+    temb = t_emb + p_emb
+    enc = _lin(enc_in, P, "context_embedder")
+    for i in range(cfg.num_layers):
+        enc, x = sd3_block(P, f"transformer_blocks.{i}.", cfg.num_attention_heads, x, enc, temb, dual=i in cfg.dual_attention_layers,
+                           context_pre_only=i == cfg.num_layers - 1, attn_kw=attn_kw)
+        if features is not None:
+            features[i] = x
+    sc, sh = _lin(F.silu(temb), P, "norm_out.linear").chunk(2, dim=1)
+    x = _ln(x) * (1 + sc[:, None]) + sh[:, None]
+    x = _lin(x, P, "proj_out").reshape(B, hp, wp, p, p, cfg.out_channels)
+    return torch.einsum("nhwpqc->nchpwq", x).reshape(B, cfg.out_channels, hp * p, wp * p)

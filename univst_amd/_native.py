@@ -69,7 +69,12 @@ SIGNATURES = {
     "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
     "univst_sd3_adain_shift": (_I, [_P, _L, _I, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_rmsnorm_heads": (_I, [_P, _L, _L, _I, _I, _P, _F, _P]),
-    "univst_adaln_modulate": (_I, [_P, _P, _P, _P, _L, _L, _I, _F, _P]),
+    "univst_adaln_modulate": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _F, _P, _P, _P, _P]),
+    "univst_gate_residual": (_I, [_P, _P, _L, _P, _P, _L, _L, _I, _P]),
+    "univst_activation": (_I, [_P, _P, _L, _I, _P]),
+    "univst_timestep_embedding": (_I, [_P, _P, _I, _I, _I, _F, _F, _P]),
+    "univst_sd3_patchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "univst_sd3_unpatchify": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "univst_axpbypcz": (_I, [_P, _P, _P, _P, _F, _F, _F, _L, _P]),
     "univst_attention_adain_shift": (_I, [_P, _L, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_latent_adain": (_I, [_P, _P, _P, _I, _I, _I, _P]),
@@ -284,13 +289,80 @@ def rmsnorm_heads_(x, heads, weight, eps=1e-6):
     return x
 
 
-def adaln_modulate(x, scale, shift, eps=1e-6):
-    """x [B, N, C], scale / shift [B, C] -> LayerNorm(x) * (1 + scale) + shift."""
-    _f16(x), _f16(scale), _f16(shift)
+def _mod_ld(*ts):
+    """scale / shift / gate operands are [B, C] views into one [B, k*C] adaLN output: same row stride, unit column stride."""
+    ld = ts[0].stride(0)
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float16):
+            raise ValueError(f"modulation operand: expected an fp16 CUDA/HIP tensor, got {t.dtype} {t.device}")
+        if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) != ld:
+            raise ValueError("modulation operands must be [B, C] row views with a common row stride")
+    return ld
+
+
+def adaln_modulate(x, scale, shift, eps=1e-6, scale2=None, shift2=None):
+    """x [B, N, C], scale / shift [B, C] (row views allowed) -> LayerNorm(x) * (1 + scale) + shift; with scale2 / shift2 also the
+    second modulation of the same normalised rows (AdaLayerNormZeroX) -> (y, y2)."""
+    _f16(x)
     B, N, Cc = x.shape
+    if not x.is_contiguous():
+        raise ValueError("adaln_modulate: x must be contiguous")
+    two = scale2 is not None
+    ld = _mod_ld(scale, shift, *([scale2, shift2] if two else []))
     out = torch.empty_like(x)
-    check(load().univst_adaln_modulate(ptr(x), ptr(out), ptr(scale), ptr(shift), B * N, N, Cc, eps, stream_ptr()), "adaln_modulate")
+    out2 = torch.empty_like(x) if two else None
+    check(load().univst_adaln_modulate(ptr(x), ptr(out), ptr(scale), ptr(shift), ld, B * N, N, Cc, eps, ptr(out2), ptr(scale2), ptr(shift2),
+                                       stream_ptr()), "adaln_modulate")
+    return (out, out2) if two else out
+
+
+def gate_residual(x, gate, y, out=None):
+    """x + gate[:, None] * y for x, y [B, N, C], gate [B, C] (row view allowed)."""
+    _f16(x), _f16(y)
+    B, N, Cc = x.shape
+    if not (x.is_contiguous() and y.is_contiguous()):
+        raise ValueError("gate_residual: x and y must be contiguous")
+    out = torch.empty_like(x) if out is None else out
+    check(load().univst_gate_residual(ptr(x), ptr(gate), _mod_ld(gate), ptr(y), ptr(out), B * N, N, Cc, stream_ptr()), "gate_residual")
     return out
+
+
+ACT_SILU, ACT_GELU_TANH = 0, 1
+
+
+def activation(x, act, out=None):
+    _f16(x)
+    if not x.is_contiguous():
+        raise ValueError("activation: x must be contiguous")
+    out = torch.empty_like(x) if out is None else out
+    check(load().univst_activation(ptr(x), ptr(out), x.numel(), act, stream_ptr()), "activation")
+    return out
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0.0, max_period=10000.0):
+    """t [B] (any float dtype, device) -> [B, dim] fp16 sinusoidal embedding (diffusers Timesteps)."""
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float16)
+    check(load().univst_timestep_embedding(ptr(t), ptr(out), t.shape[0], dim, int(flip_sin_to_cos), downscale_freq_shift, max_period, stream_ptr()),
+          "timestep_embedding")
+    return out
+
+
+def sd3_patchify(latents, patch):
+    """[B, C, H, W] -> [B*(H/p)*(W/p), C*p*p] (k order of the flattened PatchEmbed conv weight)."""
+    _f16(latents)
+    B, Cc, H, W = latents.shape
+    rows = torch.empty(B * (H // patch) * (W // patch), Cc * patch * patch, device=latents.device, dtype=torch.float16)
+    check(load().univst_sd3_patchify(ptr(latents.contiguous()), ptr(rows), B, Cc, H, W, patch, stream_ptr()), "sd3_patchify")
+    return rows
+
+
+def sd3_unpatchify(rows, B, Cc, H, W, patch):
+    """[B*(H/p)*(W/p), p*p*C] -> [B, C, H, W]."""
+    _f16(rows)
+    lat = torch.empty(B, Cc, H, W, device=rows.device, dtype=torch.float16)
+    check(load().univst_sd3_unpatchify(ptr(rows.contiguous()), ptr(lat), B, Cc, H, W, patch, stream_ptr()), "sd3_unpatchify")
+    return lat
 
 
 def axpbypcz(x, y, z, a, b, c, out=None):

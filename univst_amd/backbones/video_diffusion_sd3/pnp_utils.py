@@ -18,14 +18,14 @@ def _params(attn):
     return {k: v for k, v in attn.state_dict().items()}
 
 
-def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2):
+def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2, clip_length=16):
     dt, dev = hidden_states.dtype, hidden_states.device
     if dev.type != "cuda":
         raise RuntimeError("univst_amd SD3 processors run on the GPU only (no CPU path): move the tensors to cuda")
     hid = hidden_states.to(torch.float16).contiguous()
     enc = None if encoder_hidden_states is None else encoder_hidden_states.to(torch.float16).contiguous()
     eps = getattr(getattr(attn, "norm_q", None), "eps", None) or 1e-6
-    out = _native.sd3_joint_attention(_params(attn), hid, enc, attn.heads, clip_length=16, shift=shift, idx=idx, eta1=eta1, eta2=eta2,
+    out = _native.sd3_joint_attention(_params(attn), hid, enc, attn.heads, clip_length=clip_length, shift=shift, idx=idx, eta1=eta1, eta2=eta2,
                                       rms_eps=float(eps))
     if enc is None:
         return out.to(dt)

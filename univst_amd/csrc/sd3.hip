@@ -95,35 +95,143 @@ __global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv
 }
 
 // src_idx [B][3] = ['first', f-1 (clipped), f] of the frame's own clip, x_idx [B] = the frame itself (pnp_utils.py:27,53-78)
+// clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): src_idx [B][1] = the frame itself
 __global__ void sd3_index_kernel(int B, int clip, int* __restrict__ src_idx, int* __restrict__ x_idx) {
     const int bf = blockIdx.x * blockDim.x + threadIdx.x;
     if (bf >= B) return;
+    x_idx[bf] = bf;
+    if (clip == 0) {
+        src_idx[bf] = bf;
+        return;
+    }
     const int b = bf / clip, f = bf - b * clip;
     src_idx[bf * 3 + 0] = b * clip;
     src_idx[bf * 3 + 1] = b * clip + (f > 0 ? f - 1 : 0);
     src_idx[bf * 3 + 2] = bf;
-    x_idx[bf] = bf;
 }
 
-// y = LN(x) * (1 + scale[b]) + shift[b]; one wave per row, C <= 4096
+// y = LN(x) * (1 + scale[b]) + shift[b] (and optionally y2 with a second (scale2, shift2) from the SAME normalised row:
+// AdaLayerNormZeroX of the dual-attention blocks); one wave per row held in registers, C <= 4096, C % 8 == 0; scale / shift rows
+// are ld_mod halfs apart (they are chunks of one [B, 6C | 9C | 2C] linear output)
 __global__ __launch_bounds__(256) void adaln_modulate_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const half_t* __restrict__ scale,
-                                                             const half_t* __restrict__ shift, long rows, long rows_per_batch, int C, float eps) {
+                                                             const half_t* __restrict__ shift, long ld_mod, long rows, long rows_per_batch, int C,
+                                                             float eps, half_t* __restrict__ y2, const half_t* __restrict__ scale2,
+                                                             const half_t* __restrict__ shift2) {
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
     const long b = r / rows_per_batch;
     const half_t* xr = x + r * C;
+    h8 v[8];
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += (float)xr[c];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < C) {
+            v[i] = *reinterpret_cast<const h8*>(xr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+        }
+    }
     const float mu = wave_sum(s) / C;
     float q = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float dl = (float)xr[c] - mu;
-        q += dl * dl;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dl = (float)v[i][e] - mu;
+                q += dl * dl;
+            }
+        }
     }
     const float rs = rsqrtf(wave_sum(q) / C + eps);
-    for (int c = lane; c < C; c += 64)
-        y[r * C + c] = (half_t)(((float)xr[c] - mu) * rs * (1.f + (float)scale[b * C + c]) + (float)shift[b * C + c]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < C) {
+            const h8 sc = *reinterpret_cast<const h8*>(scale + b * ld_mod + c), sh = *reinterpret_cast<const h8*>(shift + b * ld_mod + c);
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mu) * rs * (1.f + (float)sc[e]) + (float)sh[e]);
+            *reinterpret_cast<h8*>(y + r * C + c) = o;
+            if (y2) {
+                const h8 sc2 = *reinterpret_cast<const h8*>(scale2 + b * ld_mod + c), sh2 = *reinterpret_cast<const h8*>(shift2 + b * ld_mod + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v[i][e] - mu) * rs * (1.f + (float)sc2[e]) + (float)sh2[e]);
+                *reinterpret_cast<h8*>(y2 + r * C + c) = o;
+            }
+        }
+    }
+}
+
+// out[r, c] = x[r, c] + gate[b(r), c] * y[r, c]  (the gated residuals of the MM-DiT block; gate rows ld_gate halfs apart); C % 8 == 0
+__global__ __launch_bounds__(256) void gate_residual_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gate, long ld_gate,
+                                                            const half_t* __restrict__ y, half_t* __restrict__ out, long rows, long rows_per_batch,
+                                                            int C) {
+    const int c8 = C / 8;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * c8) return;
+    const long r = i / c8;
+    const int c = (int)(i - r * c8) * 8;
+    const long b = r / rows_per_batch;
+    const h8 xv = *reinterpret_cast<const h8*>(x + r * C + c), yv = *reinterpret_cast<const h8*>(y + r * C + c);
+    const h8 gv = *reinterpret_cast<const h8*>(gate + b * ld_gate + c);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)fmaf((float)gv[e], (float)yv[e], (float)xv[e]);
+    *reinterpret_cast<h8*>(out + r * C + c) = o;
+}
+
+// act 0: SiLU  x * sigmoid(x);  act 1: GELU(tanh)  0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))   (torch gelu approximate='tanh')
+template <int ACT>
+__global__ __launch_bounds__(256) void act_kernel(const half_t* __restrict__ x, half_t* __restrict__ out, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const h8 v = reinterpret_cast<const h8*>(x)[i];
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = (float)v[e];
+        if (ACT == 0) o[e] = (half_t)(t / (1.f + __expf(-t)));
+        else {
+            const float u = 0.7978845608028654f * fmaf(0.044715f * t * t, t, t);
+            o[e] = (half_t)(0.5f * t * (1.f + tanhf(u)));
+        }
+    }
+    reinterpret_cast<h8*>(out)[i] = o;
+}
+
+// diffusers get_timestep_embedding(t, dim, flip_sin_to_cos, downscale_freq_shift, scale 1, max_period 10000) in fp32, stored fp16:
+// freq_i = exp(-ln(max_period) * i / (dim/2 - shift)); [sin | cos] halves, swapped when flip
+__global__ void timestep_embed_kernel(const float* __restrict__ t, half_t* __restrict__ out, int B, int dim, int flip, float shift, float max_period) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half_dim = dim / 2;
+    if (i >= B * half_dim) return;
+    const int b = i / half_dim, j = i - b * half_dim;
+    const float freq = expf(-logf(max_period) * (float)j / ((float)half_dim - shift));
+    const float a = t[b] * freq;
+    const float sn = sinf(a), cs = cosf(a);
+    out[(long)b * dim + j] = (half_t)(flip ? cs : sn);
+    out[(long)b * dim + half_dim + j] = (half_t)(flip ? sn : cs);
+}
+
+// PatchEmbed's Conv2d(Cc, D, kernel p, stride p) as a linear: rows[(b, i, j)][c*p*p + u*p + v] = lat[b, c, i*p + u, j*p + v]
+// (k index order = the flattened conv weight [D][Cc][p][p]); FORWARD: latent -> rows, else rows -> latent (unpatchify: the row holds
+// [u][v][c] as diffusers' reshape (h, w, p, p, c) -> einsum nhwpqc->nchpwq does)
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void patch_kernel(half_t* __restrict__ lat, half_t* __restrict__ rowsb, int B, int Cc, int H, int W, int P) {
+    const long n = (long)B * Cc * H * W;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int w = (int)(i % W), h = (int)(i / W % H), c = (int)(i / ((long)W * H) % Cc);
+    const long b = i / ((long)W * H * Cc);
+    const int pi = h / P, u = h - pi * P, pj = w / P, v = w - pj * P;
+    const long row = (b * (H / P) + pi) * (W / P) + pj;
+    const int K = Cc * P * P;
+    if (FORWARD) rowsb[row * K + (c * P + u) * P + v] = lat[i];
+    else lat[i] = rowsb[row * K + (u * P + v) * Cc + c];
 }
 
 __global__ void axpbypcz_kernel(const half_t* __restrict__ x, const half_t* __restrict__ y, const half_t* __restrict__ z,
@@ -156,11 +264,63 @@ int univst_rmsnorm_heads(void* x, int64_t ld, int64_t rows, int heads, int d, co
     return UV_OK;
 }
 
-int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t rows, int64_t rows_per_batch, int C, float eps,
-                          void* stream) {
-    UV_REQUIRE(x && y && scale && shift && rows >= 1 && rows_per_batch >= 1 && C >= 1, "adaln_modulate: bad argument");
+int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t ld_mod, int64_t rows, int64_t rows_per_batch,
+                          int C, float eps, void* y2, const void* scale2, const void* shift2, void* stream) {
+    UV_REQUIRE(x && y && scale && shift && rows >= 1 && rows_per_batch >= 1 && C >= 8 && C % 8 == 0 && C <= 4096 && ld_mod % 8 == 0 && ld_mod >= C,
+               "adaln_modulate: bad argument (C=%d must be a multiple of 8, <= 4096; ld_mod=%ld)", C, (long)ld_mod);
+    UV_REQUIRE(!y2 || (scale2 && shift2), "adaln_modulate: y2 needs scale2 and shift2");
     hipLaunchKernelGGL(adaln_modulate_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)y,
-                       (const half_t*)scale, (const half_t*)shift, rows, rows_per_batch, C, eps);
+                       (const half_t*)scale, (const half_t*)shift, (long)ld_mod, (long)rows, (long)rows_per_batch, C, eps, (half_t*)y2,
+                       (const half_t*)scale2, (const half_t*)shift2);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_gate_residual(const void* x, const void* gate, int64_t ld_gate, const void* y, void* out, int64_t rows, int64_t rows_per_batch, int C,
+                         void* stream) {
+    UV_REQUIRE(x && gate && y && out && rows >= 1 && rows_per_batch >= 1 && C >= 8 && C % 8 == 0 && ld_gate % 8 == 0, "gate_residual: bad argument");
+    const long n = rows * (C / 8);
+    hipLaunchKernelGGL(gate_residual_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (const half_t*)gate, (long)ld_gate, (const half_t*)y, (half_t*)out, (long)rows, (long)rows_per_batch, C);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_activation(const void* x, void* out, int64_t n, int act, void* stream) {
+    UV_REQUIRE(x && out && n >= 8 && n % 8 == 0 && (act == UNIVST_ACT_SILU || act == UNIVST_ACT_GELU_TANH), "activation: bad argument");
+    const long n8 = n / 8;
+    if (act == UNIVST_ACT_SILU)
+        hipLaunchKernelGGL(act_kernel<0>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)out, n8);
+    else
+        hipLaunchKernelGGL(act_kernel<1>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, (half_t*)out, n8);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_timestep_embedding(const float* t, void* out, int B, int dim, int flip_sin_to_cos, float downscale_freq_shift, float max_period,
+                              void* stream) {
+    UV_REQUIRE(t && out && B >= 1 && dim >= 2 && dim % 2 == 0 && max_period > 1.f, "timestep_embedding: bad argument");
+    const int n = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, (hipStream_t)stream, t, (half_t*)out, B, dim,
+                       flip_sin_to_cos, downscale_freq_shift, max_period);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_sd3_patchify(const void* latents, void* rows, int B, int C, int H, int W, int patch, void* stream) {
+    UV_REQUIRE(latents && rows && B >= 1 && C >= 1 && patch >= 1 && H % patch == 0 && W % patch == 0, "sd3_patchify: bad argument");
+    const long n = (long)B * C * H * W;
+    hipLaunchKernelGGL(patch_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (half_t*)latents, (half_t*)rows, B, C,
+                       H, W, patch);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
+int univst_sd3_unpatchify(const void* rows, void* latents, int B, int C, int H, int W, int patch, void* stream) {
+    UV_REQUIRE(latents && rows && B >= 1 && C >= 1 && patch >= 1 && H % patch == 0 && W % patch == 0, "sd3_unpatchify: bad argument");
+    const long n = (long)B * C * H * W;
+    hipLaunchKernelGGL(patch_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (half_t*)latents, (half_t*)rows, B, C,
+                       H, W, patch);
     UV_LAUNCH_CHECK();
     return UV_OK;
 }
@@ -196,7 +356,8 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
     hipStream_t s = (hipStream_t)stream;
     UV_REQUIRE(w && hidden && out_img && B >= 1 && N >= 1 && heads >= 1, "sd3_joint_attention: null / empty argument");
     UV_REQUIRE(w->to_q && w->to_k && w->to_v && w->to_out, "sd3_joint_attention: to_q / to_k / to_v / to_out weights are required");
-    UV_REQUIRE(clip_length >= 1 && B % clip_length == 0, "sd3_joint_attention: batch %d is not a whole number of %d-frame clips", B, clip_length);
+    UV_REQUIRE(clip_length >= 0 && (clip_length == 0 || B % clip_length == 0), "sd3_joint_attention: batch %d is not a whole number of %d-frame clips",
+               B, clip_length);
     UV_REQUIRE(!shift || B % 3 == 0, "sd3_joint_attention: the attention shift needs the three-branch batch");
     UV_REQUIRE(!enc || (out_txt && Nt >= 1 && w->add_q && w->add_k && w->add_v), "sd3_joint_attention: text tokens need add_{q,k,v}_proj and out_txt");
     const int C = heads * head_dim;
@@ -240,7 +401,7 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         UV_LAUNCH_CHECK();
         AttnParams a;
         a.k = qkv_i + C; a.v = qkv_i + 2 * C; a.ldkv = 3 * C;
-        a.src_idx = tab; a.nsrc = 3; a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
+        a.src_idx = tab; a.nsrc = clip_length ? 3 : 1; a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
         a.scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
         if (enc) { a.kx = qkv_t + C; a.vx = qkv_t + 2 * C; a.ldkv_x = 3 * C; a.Nkv_x = Nt; a.x_idx = tab + 3 * B; }
         a.q = qkv_i; a.ldq = 3 * C; a.Nq = N; a.o = o_i; a.ldo = C;
