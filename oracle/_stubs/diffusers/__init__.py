@@ -15,5 +15,6 @@ class ModelMixin(nn.Module):
         return next(self.parameters()).device
 
 
-from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: E402
+from .schedulers import DDIMScheduler, DDPMScheduler, FlowMatchEulerDiscreteScheduler  # noqa: E402
 from .models import AutoencoderKL, AutoencoderKLTemporalDecoder  # noqa: E402
+from .pipelines.stable_diffusion_3 import StableDiffusion3Pipeline  # noqa: E402

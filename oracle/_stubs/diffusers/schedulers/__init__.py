@@ -75,3 +75,42 @@ class EulerAncestralDiscreteScheduler: pass
 class EulerDiscreteScheduler: pass
 class LMSDiscreteScheduler: pass
 class PNDMScheduler: pass
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """diffusers 0.35.1 FlowMatchEulerDiscreteScheduler restated for the SD3 / SD3.5 scheduler_config.json (shift 3.0,
+    use_dynamic_shifting False): the table construction and the Euler `step`.  Third-party stand-in, parity unpinned."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, shift=3.0):
+        self._internal_dict = FrozenDict(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=False)
+        self.shift = shift
+        s = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy() / num_train_timesteps
+        s = shift * s / (1 + (shift - 1) * s)
+        self.sigma_min, self.sigma_max = float(s[-1]), float(s[0])
+        self.sigmas = torch.from_numpy(s)
+        self.timesteps = self.sigmas * num_train_timesteps
+        self._step_index = None
+
+    @property
+    def config(self):
+        return self._internal_dict
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        T = self.config.num_train_timesteps
+        if sigmas is None:
+            sigmas = np.linspace(self.sigma_max * T, self.sigma_min * T, num_inference_steps) / T
+        sigmas = np.asarray(sigmas, dtype=np.float32)
+        sigmas = (self.shift * sigmas / (1 + (self.shift - 1) * sigmas)).astype(np.float32)
+        sig = torch.from_numpy(sigmas)
+        self.timesteps = sig * T
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self._step_index = None
+
+    def step(self, model_output, timestep, sample, return_dict=True, **kw):
+        if self._step_index is None:
+            self._step_index = int((self.timesteps == timestep).nonzero()[0])
+        sample = sample.to(torch.float32)
+        prev = sample + (self.sigmas[self._step_index + 1] - self.sigmas[self._step_index]) * model_output
+        self._step_index += 1
+        return (prev.to(model_output.dtype),)

@@ -267,3 +267,93 @@ def sd3_transformer(P: Dict[str, torch.Tensor], cfg, latents, enc_in, pooled, ti
     x = _ln(x) * (1 + sc[:, None]) + sh[:, None]
     x = _lin(x, P, "proj_out").reshape(B, hp, wp, p, p, cfg.out_channels)
     return torch.einsum("nhwpqc->nchpwq", x).reshape(B, cfg.out_channels, hp * p, wp * p)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The SD3 pipeline's loops (backbones/video_diffusion_sd3/pipelines/custom_pipeline.py) — REFERENCE-OWNED, pinned by golden G19 (the
+# reference's own `reconstruction` and `video_style_transfer` run over a closed-form velocity field and the restated
+# FlowMatchEuler tables).  Fixed reading of the second defect at HEAD: the undefined name `ddim_inv_latents_at_t` (:303) is the
+# content inversion latent of the step (what the SD-v1.5 loop blends at the same place); in the no-mask loop that G19 pins it is
+# multiplied by 0.0.
+def generate_eta_values(timesteps, start_step: int, end_step: int, eta: float, eta_trend: str) -> List[float]:
+    """custom_pipeline.py:18-43"""
+    assert 0 <= start_step < end_step <= len(timesteps)
+    out = [0.0] * len(timesteps)
+    total = timesteps[start_step] - timesteps[end_step - 1]
+    for i in range(start_step, end_step):
+        if eta_trend == "constant":
+            out[i] = eta
+        elif eta_trend == "linear_increase":
+            out[i] = eta * (timesteps[start_step] - timesteps[i]) / total
+        elif eta_trend == "linear_decrease":
+            out[i] = eta * (timesteps[i] - timesteps[end_step - 1]) / total
+        else:
+            raise NotImplementedError(eta_trend)
+    return out
+
+
+def flow_match_schedule(n: int, shift: float = 3.0, T: int = 1000):
+    """diffusers 0.35.1 FlowMatchEulerDiscreteScheduler (SD3 config): __init__ shifts sigma = t/T once (sigma_max 1, sigma_min =
+    shifted 1/T); set_timesteps(n) takes linspace(sigma_max, sigma_min, n) and applies the shift AGAIN; trailing 0.  Third-party,
+    parity unpinned.  (`flow_match_sigmas` above is the simplified table golden G17 was generated with; it differs from this one only
+    in the position of the last node.)  -> (timesteps [n], sigmas [n+1]) fp32"""
+    import numpy as np
+    s0 = np.linspace(1, T, T, dtype=np.float32)[::-1].copy() / T                  # __init__: fp32 table, shifted once
+    s0 = shift * s0 / (1 + (shift - 1) * s0)
+    smax, smin = float(s0[0]), float(s0[-1])
+    s = (np.linspace(smax * T, smin * T, n) / T).astype(np.float32)               # set_timesteps: float64 linspace, fp32 from here on
+    sig = torch.from_numpy((shift * s / (1 + (shift - 1) * s)).astype(np.float32))
+    return sig * T, torch.cat([sig, torch.zeros(1)])
+
+
+def toy_velocity(x: torch.Tensor, t1000: torch.Tensor, idx: int, frames: int) -> torch.Tensor:
+    """closed-form stand-in for the transformer on the three-branch batch [content | style | stylised]: the stylised branch's
+    output also reads the other two branches, so a wrong branch order or a wrong chunk shows."""
+    tt = float(t1000.reshape(-1)[0]) / 1000.0
+    v = torch.tanh(0.7 * x.flip(-1)) * (0.5 + tt) - 0.3 * x + 0.01 * idx
+    if x.shape[0] == 3 * frames:
+        v = torch.cat([v[:2 * frames], v[2 * frames:] + 0.2 * x[:frames] - 0.1 * x[frames:2 * frames]])
+    return v
+
+
+def toy_loop_inputs(seed: int = 1901, frames: int = 4, ch: int = 4, hw: int = 6, n: int = 50):
+    g = torch.Generator().manual_seed(seed)
+    content = [torch.randn(frames, ch, hw, hw, generator=g) * (0.3 + 0.7 * k / n) for k in range(n + 1)]       # k = 0: the clean latents
+    style = [0.2 + 1.3 * torch.randn(frames, ch, hw, hw, generator=g) * (0.3 + 0.7 * k / n) for k in range(n + 1)]
+    mask = (torch.rand(1, frames, 8 * hw, 8 * hw, generator=g) > 0.6).to(torch.uint8)
+    return dict(content=content, style=style, mask=mask)
+
+
+def sd3_reconstruction_loop(velocity_fn: Callable, img_latents, inversed_latents, timesteps, sigmas, eta_values, T: int = 1000):
+    """custom_pipeline.py:88-118 (guidance_scale 1.0): fp32 latents, v' = v + eta (-(target - x)/t - v), Euler step.  The
+    transformer is called WITHOUT joint_attention_kwargs here (:96-102): velocity_fn sees step index 0 throughout."""
+    x, target = inversed_latents.float(), img_latents.float()
+    for i, t in enumerate(timesteps):
+        v = velocity_fn(x, t.expand(x.shape[0]), 0).float()
+        tv = -(target - x) / (t / T)
+        v = v + eta_values[i] * (tv - v)
+        x = x + (sigmas[i + 1] - sigmas[i]) * v
+    return x
+
+
+def sd3_transfer_loop(velocity_fn: Callable, latents, img_latents, content_inv, style_inv, timesteps, sigmas, eta_values, mask=None,
+                      T: int = 1000):
+    """custom_pipeline.py:284-335.  latents [F, C, h, w]; content_inv / style_inv: lists indexed by the file label k (50 - i is read
+    at step i); mask [1, F, H, W] {0,1} or None; velocity_fn(x [3F, ...], t [3F], i) -> v."""
+    n = len(timesteps)
+    x, target = latents, img_latents.clone()
+    rm = None
+    if mask is not None:
+        rm = F.interpolate(mask.to(x.dtype), size=x.shape[-2:], mode="bilinear", align_corners=False).permute(1, 0, 2, 3).contiguous()
+    for i, t in enumerate(timesteps):
+        c_t, s_t = content_inv[50 - i].to(x.dtype), style_inv[50 - i].to(x.dtype)
+        if rm is not None and i <= 0.9 * n:
+            x = (1 - rm) * x + rm * c_t
+        if i >= 0.8 * n and i <= 0.9 * n:
+            m = rm if rm is not None else 0.0
+            x = (1.0 - m) * latent_adain(x, s_t) + m * c_t          # fixed reading of `ddim_inv_latents_at_t`
+        v = velocity_fn(torch.cat([c_t, s_t, x]), t.expand(3 * x.shape[0]), i)[2 * x.shape[0]:]
+        tv = -(target - x) / (t / T)
+        v = v + eta_values[i] * (tv - v)
+        x = (x.float() + (sigmas[i + 1] - sigmas[i]) * v).to(v.dtype)
+    return x

@@ -607,6 +607,60 @@ def main():
         chk("sd3_g18_attention_adain", g18["attention_adain"]["out"], sd3_ref.attention_adain(kk18, ks18))
     gold["g18_sd3_processors_hd64"] = g18
 
+    # ---- G19 (round 3): the SD3 pipeline's own loops — CustomStableDiffusion3Pipeline.reconstruction (custom_pipeline.py:45-124) and
+    #      .video_style_transfer (:126-346) — over a closed-form velocity field (oracle/sd3_ref.toy_velocity) and the stub scheduler.
+    #      video_style_transfer reads an undefined name in the latent-AdaIN window (:303); the generator DEFINES it
+    #      as a module global (zeros) before calling — in the no-mask loop the term is multiplied by 0.0, so its value is irrelevant —
+    #      no reference code is edited or copied.
+    import diffusers as _dstub
+    from backbones.video_diffusion_sd3.pipelines import custom_pipeline as ref_pipe
+    ref_pipe.ddim_inv_latents_at_t = torch.zeros(1)
+    ti = sd3_ref.toy_loop_inputs()
+    Fr = ti["content"][0].shape[0]
+
+    class ToyTransformer:
+        config = types.SimpleNamespace(in_channels=4, patch_size=2)
+
+        def __call__(self, hidden_states, timestep, encoder_hidden_states=None, pooled_projections=None, return_dict=False,
+                     joint_attention_kwargs=None):
+            idx = (joint_attention_kwargs or {}).get("idx", 0)
+            return (sd3_ref.toy_velocity(hidden_states, timestep, idx, Fr),)
+
+    g19 = {}
+    with tempfile.TemporaryDirectory() as td, torch.no_grad():
+        cdir, sdir = os.path.join(td, "c"), os.path.join(td, "s")
+        os.makedirs(cdir), os.makedirs(sdir)
+        for kk in range(51):
+            torch.save(ti["content"][kk], os.path.join(cdir, f"ddim_latents_{kk}.pt"))
+            torch.save(ti["style"][kk], os.path.join(sdir, f"ddim_latents_{kk}.pt"))
+        pipe19 = ref_pipe.CustomStableDiffusion3Pipeline(transformer=ToyTransformer(), scheduler=_dstub.FlowMatchEulerDiscreteScheduler())
+        pipe19.fixed_prompt = (torch.zeros(1, 3, 8), torch.zeros(1, 8))
+        start = sd3_ref.latent_adain(ti["content"][50], ti["style"][50])
+        out = pipe19.video_style_transfer("", latents=start.clone(), img_latents=ti["content"][0].clone(), num_inference_steps=50,
+                                          content_inv_path=cdir, style_inv_path=sdir, mask_path=None, eta_base=0.85, eta_trend="constant",
+                                          start_step=25, end_step=39, output_type="latent").images
+        ts19, sig19 = sd3_ref.flow_match_schedule(50)
+        assert torch.equal(ts19, pipe19.scheduler.timesteps) and torch.equal(sig19, pipe19.scheduler.sigmas)
+        eta19 = sd3_ref.generate_eta_values(ts19, 25, 39, 0.85, "constant")
+        vf = lambda x, t, i: sd3_ref.toy_velocity(x, t, i, Fr)          # noqa: E731
+        mine = sd3_ref.sd3_transfer_loop(vf, start.clone(), ti["content"][0], ti["content"], ti["style"], ts19, sig19, eta19)
+        chk("sd3_g19_video_style_transfer", out, mine)
+        g19["video_style_transfer"] = out
+        for trend in ("linear_increase", "linear_decrease"):
+            e_ref = pipe19.generate_eta_values(ts19, 10, 20, 0.95, trend)
+            e_me = sd3_ref.generate_eta_values(ts19, 10, 20, 0.95, trend)
+            chk(f"sd3_g19_eta_{trend}", torch.tensor([float(v) for v in e_ref]), torch.tensor([float(v) for v in e_me]))
+            g19[f"eta_{trend}"] = torch.tensor([float(v) for v in e_ref])
+        # reconstruction ends in vae.decode + image_processor.postprocess: identity stand-ins hand the latents back
+        pipe19.vae = types.SimpleNamespace(config=types.SimpleNamespace(scaling_factor=1.0, shift_factor=0.0), decode=lambda z: (z,))
+        pipe19.image_processor = types.SimpleNamespace(postprocess=lambda im, output_type="pil": im)
+        rec = pipe19.reconstruction(ti["content"][0].clone(), ti["content"][50].clone(), 0.85, "constant", 25, 39, guidance_scale=1.0, prompt="",
+                                    DTYPE=torch.float32, num_inference_steps=50)
+        mine = sd3_ref.sd3_reconstruction_loop(vf, ti["content"][0], ti["content"][50], ts19, sig19, eta19)
+        chk("sd3_g19_reconstruction", rec, mine)
+        g19["reconstruction"] = rec
+    gold["g19_sd3_pipeline_loops"] = g19
+
     for k, v in gold.items():
         torch.save(v, os.path.join(OUT, k + ".pt"))
     with open(os.path.join(OUT, "REPORT.txt"), "w") as f:

@@ -32,6 +32,10 @@ SURFACE = {
                                                  "attention_adain", "latent_adain"]),                                                      # video_diffusion_sd3/pnp_utils.py:9,135,276,289,305
     "inversion_tools.flow_inversion": ("univst_amd.inversion_tools.flow_inversion",
                                        ["rf_inversion", "rf_solver", "content_inversion_reconstruction", "style_inversion_reconstruction"]),  # flow_inversion.py:16-264
+    "backbones.video_diffusion_sd3.models.transformer_3D_model": ("univst_amd.backbones.video_diffusion_sd3.models.transformer_3D_model",
+                                                                  ["CustomSD3Transformer2DModel"]),                                        # transformer_3D_model.py:12
+    "backbones.video_diffusion_sd3.pipelines.custom_pipeline": ("univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline",
+                                                                ["CustomStableDiffusion3Pipeline"]),                                      # custom_pipeline.py:17
 }
 
 
@@ -47,10 +51,12 @@ def test_reference_import_paths_resolve_to_the_native_package(ref_path):
         assert getattr(shim, n) is getattr(prod, n), f"{ref_path}.{n} is not the native implementation's"
 
 
-@pytest.mark.parametrize("script", ["run_content_inversion_sd", "run_style_inversion_sd", "run_video_style_transfer_sd"])
+@pytest.mark.parametrize("script", ["run_content_inversion_sd", "run_style_inversion_sd", "run_video_style_transfer_sd",
+                                    "run_content_inversion_sd3", "run_style_inversion_sd3", "run_video_style_transfer_sd3"])
 def test_cli_scripts_keep_the_reference_flags(script):
-    """src/sd/run_*_sd.py --help works without a GPU and lists the reference's flags (run_*_sd.py argparse blocks)."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "src", "sd", script + ".py"), "--help"], capture_output=True, text=True,
+    """src/sd/run_*_sd.py and src/sd3/run_*_sd3.py --help work without a GPU and list the reference's flags (their argparse blocks)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "src", "sd3" if script.endswith("sd3") else "sd", script + ".py"), "--help"],
+                         capture_output=True, text=True,
                          cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT), timeout=120)
     assert out.returncode == 0, out.stderr[-400:]
     # the argparse blocks of the reference's three scripts (src/sd/run_*_sd.py)
@@ -59,7 +65,13 @@ def test_cli_scripts_keep_the_reference_flags(script):
             "run_style_inversion_sd": ["--pretrained_model_path", "--style_path", "--output_path", "--weight_dtype", "--num_frames", "--height",
                                        "--width", "--time_steps", "--is_opt", "--seed"],
             "run_video_style_transfer_sd": ["--pretrained_model_path", "--content_inv_path", "--style_inv_path", "--mask_path", "--output_path",
-                                            "--weight_dtype", "--time_steps", "--seed"]}[script]
+                                            "--weight_dtype", "--time_steps", "--seed"],
+            "run_content_inversion_sd3": ["--pretrained_model_path", "--content_path", "--output_path", "--weight_dtype", "--num_frames", "--height",
+                                          "--width", "--time_steps", "--ft_indices", "--ft_timesteps", "--is_rf_solver", "--seed"],
+            "run_style_inversion_sd3": ["--pretrained_model_path", "--style_path", "--output_path", "--weight_dtype", "--num_frames", "--height",
+                                        "--width", "--time_steps", "--is_rf_solver", "--seed"],
+            "run_video_style_transfer_sd3": ["--pretrained_model_path", "--content_inv_path", "--style_inv_path", "--mask_path", "--output_path",
+                                             "--weight_dtype", "--time_steps", "--seed"]}[script]
     for flag in want:
         assert flag in out.stdout, f"{script}: flag {flag} missing from --help"
 

@@ -141,8 +141,6 @@ def test_rectified_flow_inversions_match_reference_golden_g17(golden, tmp_path):
     zS = fi.rf_solver(Pipe(), z0.clone(), num_inference_steps=10)
     mx, rms = errs(zS, g["rf_solver"]["final"])
     assert mx < 5e-3 and rms < 2e-3, (mx, rms)
-    with pytest.raises(NotImplementedError):
-        fi.content_inversion_reconstruction(None)
 
 
 def test_adaln_modulate_and_rms_norm_vs_block_restatement(nat):
@@ -266,3 +264,155 @@ def test_sd3_elementwise_operators(nat):
     back = nat.sd3_unpatchify(r2.cuda(), 3, 16, 8, 12, 2)
     want = torch.einsum("nhwpqc->nchpwq", r2.float().reshape(3, 4, 6, 2, 2, 16)).reshape(3, 16, 8, 12)
     assert torch.equal(back.float().cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# the pipeline mirror (pipelines/custom_pipeline.py): its loops against golden G19 — the reference's own video_style_transfer /
+# reconstruction over a closed-form velocity field — and, with a mask, against the G19-pinned oracle loop (fixed reading of the
+# undefined name).  The "transformer" here is a test double (torch ops on the GPU); everything the pipeline itself computes (mask
+# blend, latent AdaIN, eta-interpolated Euler step) is native.  fp16 latents over 50 steps: 6e-3 of the output scale, 2e-3 rms.
+class _ToyTransformer:
+    config = types.SimpleNamespace(in_channels=4, patch_size=2, sample_size=6, joint_attention_dim=8)
+    device = torch.device("cuda")
+
+    def __init__(self, frames):
+        self.frames, self.calls = frames, []
+
+    def __call__(self, hidden_states, timestep, encoder_hidden_states=None, pooled_projections=None, return_dict=False, joint_attention_kwargs=None):
+        idx = (joint_attention_kwargs or {}).get("idx", 0)
+        self.calls.append((tuple(hidden_states.shape), tuple(encoder_hidden_states.shape), tuple(pooled_projections.shape), idx))
+        return (sd3_ref.toy_velocity(hidden_states.float(), timestep, idx, self.frames).half(),)
+
+
+def _sd3_pipe(frames):
+    from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
+    from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    return CustomStableDiffusion3Pipeline(transformer=_ToyTransformer(frames), scheduler=FlowMatchEulerDiscreteScheduler())
+
+
+def test_sd3_pipeline_loops_vs_g19(nat, tmp_path):
+    from PIL import Image
+    import numpy as np
+    g = torch.load("tests/golden/g19_sd3_pipeline_loops.pt", weights_only=True)
+    ti = sd3_ref.toy_loop_inputs()
+    Fr = ti["content"][0].shape[0]
+    pipe = _sd3_pipe(Fr)
+    pe, pp = torch.zeros(1, 3, 8), torch.zeros(1, 8)
+    from univst_amd.backbones.video_diffusion_sd3.pnp_utils import latent_adain
+    start = latent_adain(ti["content"][50].half().cuda(), ti["style"][50].half().cuda())
+    kw = dict(latents=start, img_latents=ti["content"][0], num_inference_steps=50, prompt_embeds=pe, pooled_prompt_embeds=pp, eta_base=0.85,
+              eta_trend="constant", start_step=25, end_step=39, output_type="latent")
+    out = pipe.video_style_transfer("", content_inv_latents=ti["content"], style_inv_latents=ti["style"], **kw).images
+    mx, rms = errs(out, g["video_style_transfer"])
+    assert mx < 6e-3 and rms < 2e-3, (mx, rms)
+    calls = pipe.transformer.calls
+    assert len(calls) == 50 and calls[7] == ((3 * Fr, 4, 6, 6), (3 * Fr, 3, 8), (3 * Fr, 8), 7)
+    # the same through files (the reference's hand-off: ddim_latents_{k}.pt, load_ddim_latents_at_t) and with a mask folder
+    cdir, sdir, mdir = tmp_path / "c", tmp_path / "s", tmp_path / "m"
+    for d in (cdir, sdir, mdir):
+        d.mkdir()
+    for k in range(51):
+        torch.save(ti["content"][k], cdir / f"ddim_latents_{k}.pt")
+        torch.save(ti["style"][k], sdir / f"ddim_latents_{k}.pt")
+    for f in range(Fr):
+        Image.fromarray((ti["mask"][0, f].numpy() * 255).astype(np.uint8)).save(mdir / ("%05d.png" % f))
+    out2 = pipe.video_style_transfer("", content_inv_path=str(cdir), style_inv_path=str(sdir), **kw).images
+    assert torch.equal(out2, out)
+    outm = pipe.video_style_transfer("", content_inv_path=str(cdir), style_inv_path=str(sdir), mask_path=str(mdir), **kw).images
+    ts, sig = sd3_ref.flow_match_schedule(50)
+    eta = sd3_ref.generate_eta_values(ts, 25, 39, 0.85, "constant")
+    vf = lambda x, t, i: sd3_ref.toy_velocity(x, t, i, Fr)          # noqa: E731
+    want = sd3_ref.sd3_transfer_loop(vf, start.float().cpu(), ti["content"][0], ti["content"], ti["style"], ts, sig, eta, mask=ti["mask"])
+    mx, rms = errs(outm, want)
+    assert mx < 6e-3 and rms < 2e-3, (mx, rms)
+    assert errs(outm, g["video_style_transfer"])[0] > 2e-2          # the mask matters
+    # reconstruction (:45-124): no idx is passed to the transformer
+    pipe2 = _sd3_pipe(Fr)
+    pipe2.encode_prompt = lambda **k: (pe, None, pp, None)
+    rec = pipe2.reconstruction(ti["content"][0], ti["content"][50], 0.85, "constant", 25, 39, prompt="", DTYPE=torch.float32, num_inference_steps=50,
+                               output_type="latent")
+    mx, rms = errs(rec, g["reconstruction"])
+    assert mx < 6e-3 and rms < 2e-3, (mx, rms)
+    assert all(c[3] == 0 for c in pipe2.transformer.calls)
+
+
+class _FakeVAE:
+    """16-channel linear stand-in for the stock SD3 AutoencoderKL (third-party, never re-implemented): 8x8 average pooling and a
+    fixed 3 -> 16 channel map; decode inverts it approximately.  Only the call sites are exercised."""
+    config = types.SimpleNamespace(scaling_factor=1.5305, shift_factor=0.0609)
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(2)
+        self.w = torch.randn(16, 3, generator=g).cuda()
+
+    def parameters(self):
+        return iter([self.w.half()])
+
+    def encode(self, px):
+        z = torch.einsum("oc,nchw->nohw", self.w, torch.nn.functional.avg_pool2d(px.float(), 8)).to(px.dtype)
+        return types.SimpleNamespace(latent_dist=types.SimpleNamespace(sample=lambda: z))
+
+    def decode(self, z, return_dict=False):
+        img = torch.einsum("co,nohw->nchw", torch.linalg.pinv(self.w), z.float())
+        return (torch.nn.functional.interpolate(img, scale_factor=8, mode="nearest").to(z.dtype),)
+
+
+def test_sd3_end_to_end_chain_through_files(nat, tmp_path):
+    """the four steps of scripts/start_sd3.sh on the native MM-DiT with stand-in VAE / prompt embeddings, through the same files:
+    content + style inversion (rf_solver, CrossFrameProcessor, feature dump) -> mask propagation on the dumped features ->
+    video_style_transfer with AttentionShiftProcessor and the propagated masks.  Plumbing check (shapes, files, flags); parity of the
+    pieces is covered above."""
+    import numpy as np
+    from PIL import Image
+    from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+    from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
+    from univst_amd.inversion_tools import flow_inversion as fi
+    from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    from univst_amd.src import mask_propagation as mp
+    from univst_amd.src.util import load_ddim_latents_at_t
+    Fr, HW = 16, 64
+    m, _ = _tiny_sd3(layers=2, dual=(0,))
+    m.set_attn_processor({n: pnp_utils.CrossFrameProcessor() for n in m.attn_processors})
+    pipe = CustomStableDiffusion3Pipeline(transformer=m, scheduler=FlowMatchEulerDiscreteScheduler(), vae=_FakeVAE())
+    g = torch.Generator().manual_seed(4)
+    pe, pp = torch.randn(1, 5, 64, generator=g).half().cuda(), torch.randn(1, 32, generator=g).half().cuda()
+    pipe.encode_prompt = lambda **k: (pe, None, pp, None)
+    cdir, sdir = tmp_path / "content", tmp_path / "style.png"
+    cdir.mkdir()
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 256, (HW, HW, 3), dtype=np.uint8)
+    for f in range(Fr):
+        Image.fromarray(np.roll(base, 2 * f, axis=1)).save(cdir / ("%05d.png" % f))
+    Image.fromarray(rng.integers(0, 256, (HW, HW, 3), dtype=np.uint8)).save(sdir)
+    out = {k: tmp_path / k for k in ("c_inv", "c_rec", "c_ft", "s_inv", "s_rec", "masks", "styl")}
+    for d in out.values():
+        d.mkdir()
+    zc = fi.content_inversion_reconstruction(pipe, str(cdir), str(out["c_inv"]), str(out["c_rec"]), Fr, HW, HW, 50, torch.float16, ft_indices=[1],
+                                             ft_timesteps=[5], ft_path=str(out["c_ft"]), is_rf_solver=True, reconstruct=False)
+    zs = fi.style_inversion_reconstruction(pipe, str(sdir), str(out["s_inv"]), str(out["s_rec"]), Fr, HW, HW, 50, torch.float16, is_rf_solver=True,
+                                           reconstruct=False)
+    assert zc.shape == (Fr, 16, 8, 8) and torch.isfinite(zc).all() and torch.isfinite(zs).all()
+    assert len(list(out["c_inv"].glob("ddim_latents_*.pt"))) == 51 and len(list(out["s_inv"].glob("ddim_latents_*.pt"))) == 51
+    ft = out["c_ft"] / "inversion_feature_map_1_block_5_step.pt"
+    assert torch.load(ft, weights_only=True).shape == (Fr, 4, 4, 128)
+    first = np.zeros((HW, HW), np.uint8)
+    first[16:48, 8:40] = 1
+    Image.fromarray(first).save(tmp_path / "first.png")
+    margs = mp.build_parser().parse_args(["--feature_path", str(ft), "--backbone", "sd3", "--mask_path", str(tmp_path / "first.png"),
+                                          "--output_path", str(out["masks"]), "--num_frames", str(Fr)])
+    mp.video_mask_propogation(margs)
+    mdir = out["masks"] / "sd3" / "first"
+    assert len(list(mdir.glob("*.png"))) == Fr
+    # step 4 (run_video_style_transfer_sd3.py:84-101)
+    noises = load_ddim_latents_at_t(50, str(out["c_inv"])).cuda()
+    snoise = load_ddim_latents_at_t(50, str(out["s_inv"])).cuda()
+    start = pnp_utils.latent_adain(noises, snoise)
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    res = pipe.video_style_transfer("", latents=start, img_latents=load_ddim_latents_at_t(0, str(out["c_inv"])), num_inference_steps=50,
+                                    content_inv_path=str(out["c_inv"]), style_inv_path=str(out["s_inv"]), mask_path=str(mdir), eta_base=0.85,
+                                    eta_trend="constant", start_step=25, end_step=39).images
+    assert len(res) == Fr and res[0].size == (HW, HW)
+    lat = pipe.video_style_transfer("", latents=start, img_latents=load_ddim_latents_at_t(0, str(out["c_inv"])), num_inference_steps=50,
+                                    content_inv_path=str(out["c_inv"]), style_inv_path=str(out["s_inv"]), mask_path=None, eta_base=0.85,
+                                    eta_trend="constant", start_step=25, end_step=39, output_type="latent").images
+    assert lat.shape == (Fr, 16, 8, 8) and torch.isfinite(lat).all()

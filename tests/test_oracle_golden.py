@@ -322,3 +322,30 @@ def test_sd3_processors_head_dim_64_g18(golden):
         assert rel(img, g[f"shift_idx{idx}"]["img"]) < TOL and rel(txt, g[f"shift_idx{idx}"]["txt"]) < TOL, idx
     a = g["attention_adain"]
     assert rel(sd3_ref.attention_adain(a["cnt"], a["sty"]), a["out"]) < TOL
+
+
+def test_sd3_pipeline_loops_g19(golden):
+    """G19: the reference's own CustomStableDiffusion3Pipeline.video_style_transfer (no mask) and .reconstruction over the closed-form
+    velocity field; eta tables; and the product's FlowMatchEuler tables equal the oracle's restatement (third-party, unpinned)."""
+    from oracle import sd3_ref
+    from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    g = golden("g19_sd3_pipeline_loops")
+    ti = sd3_ref.toy_loop_inputs()
+    Fr = ti["content"][0].shape[0]
+    ts, sig = sd3_ref.flow_match_schedule(50)
+    sch = FlowMatchEulerDiscreteScheduler()
+    sch.set_timesteps(50)
+    assert torch.equal(sch.timesteps, ts) and torch.equal(sch.sigmas, sig) and sig[-1] == 0 and abs(float(ts[-1]) - 8.9286) < 1e-3
+    eta = sd3_ref.generate_eta_values(ts, 25, 39, 0.85, "constant")
+    assert eta[24] == 0 and eta[25] == 0.85 and eta[38] == 0.85 and eta[39] == 0
+    for trend in ("linear_increase", "linear_decrease"):
+        assert rel(torch.tensor([float(v) for v in sd3_ref.generate_eta_values(ts, 10, 20, 0.95, trend)]), g[f"eta_{trend}"]) < TOL
+    vf = lambda x, t, i: sd3_ref.toy_velocity(x, t, i, Fr)          # noqa: E731
+    start = sd3_ref.latent_adain(ti["content"][50], ti["style"][50])
+    out = sd3_ref.sd3_transfer_loop(vf, start, ti["content"][0], ti["content"], ti["style"], ts, sig, eta)
+    assert rel(out, g["video_style_transfer"]) < TOL
+    rec = sd3_ref.sd3_reconstruction_loop(vf, ti["content"][0], ti["content"][50], ts, sig, eta)
+    assert rel(rec, g["reconstruction"]) < TOL
+    # the mask (fixed reading of the undefined name) changes the result, and only through the masked pixels' history
+    outm = sd3_ref.sd3_transfer_loop(vf, start, ti["content"][0], ti["content"], ti["style"], ts, sig, eta, mask=ti["mask"])
+    assert not torch.allclose(outm, out)

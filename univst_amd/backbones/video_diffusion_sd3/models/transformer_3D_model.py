@@ -298,9 +298,11 @@ class CustomSD3Transformer2DModel(nn.Module):
         B, _, height, width = x.shape
         p = self.config.patch_size
         h = self.pos_embed(x)                                        # [B, N, D] incl. positional table
-        cond = self.time_text_embed(timestep.reshape(-1).expand(B), pooled_projections.to(torch.float16).contiguous())
+        # a batch-1 prompt against F frames (rf_inversion / rf_solver / reconstruction pass it so): torch broadcasting in diffusers
+        bc = lambda t: t.expand(B, *t.shape[1:]) if t.shape[0] == 1 and B > 1 else t          # noqa: E731
+        cond = self.time_text_embed(timestep.reshape(-1).expand(B), bc(pooled_projections).to(torch.float16).contiguous())
         temb = _native.activation(cond, _native.ACT_SILU)
-        enc_in = encoder_hidden_states.to(torch.float16).contiguous()
+        enc_in = bc(encoder_hidden_states).to(torch.float16).contiguous()
         T = enc_in.shape[1]
         enc = _linear(enc_in.reshape(B * T, -1), self.context_embedder).view(B, T, -1)
         for index_block, block in enumerate(self.transformer_blocks):

@@ -69,3 +69,50 @@ class DDIMScheduler:
         if not return_dict:
             return (prev,)
         return _Cfg(prev_sample=prev, pred_original_sample=x0)
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """The schedule tables of diffusers 0.35.1 ``FlowMatchEulerDiscreteScheduler`` for the SD3 / SD3.5 configuration (shift 3.0,
+    no dynamic shifting) — THIRD-PARTY, restated from the published definition, parity unpinned (oracle/sd3_ref.flow_match_schedule is
+    the same reading).  Used when ``diffusers`` is not installed; the SD3 pipeline mirror is duck-typed and takes the real object too
+    (it reads ``timesteps``, ``sigmas``, ``config.num_train_timesteps`` and calls ``set_timesteps``).  The Euler update itself is
+    folded into one three-term kernel launch by the pipeline (custom_pipeline.py mirror); ``step`` is here for API completeness."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=False, **unused):
+        if use_dynamic_shifting:
+            raise NotImplementedError("use_dynamic_shifting (the SD3 checkpoints ship with it off)")
+        self.config = _Cfg(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=False)
+        self.shift = shift
+        s = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy() / num_train_timesteps
+        s = shift * s / (1 + (shift - 1) * s)
+        self.sigma_min, self.sigma_max = float(s[-1]), float(s[0])
+        self.timesteps = torch.from_numpy(s * num_train_timesteps)
+        self.sigmas = torch.from_numpy(s)
+        self.num_inference_steps = None
+        self._step_index = None
+
+    from_pretrained = classmethod(DDIMScheduler.from_pretrained.__func__)
+
+    def set_timesteps(self, num_inference_steps=None, device=None, sigmas=None, mu=None):
+        self.num_inference_steps = num_inference_steps
+        if sigmas is None:                   # linspace between the ALREADY shifted end points, then shifted again (as diffusers does)
+            T = self.config.num_train_timesteps
+            sigmas = np.linspace(self.sigma_max * T, self.sigma_min * T, num_inference_steps) / T
+        sigmas = np.asarray(sigmas, dtype=np.float32)
+        sigmas = (self.shift * sigmas / (1 + (self.shift - 1) * sigmas)).astype(np.float32)
+        sig = torch.from_numpy(sigmas)
+        self.timesteps = (sig * self.config.num_train_timesteps).to(device=device)
+        self.sigmas = torch.cat([sig, torch.zeros(1)]).to(device=device)
+        self._step_index = None
+
+    def step(self, model_output, timestep, sample, return_dict=True, **unused):
+        """prev = sample + (sigma_next - sigma) * model_output in fp32, cast back (Euler step of the flow ODE)."""
+        if self._step_index is None:
+            self._step_index = int((self.timesteps == timestep).nonzero()[0])
+        i = self._step_index
+        prev = (sample.float() + float(self.sigmas[i + 1] - self.sigmas[i]) * model_output.float()).to(model_output.dtype)
+        self._step_index += 1
+        if not return_dict:
+            return (prev,)
+        return _Cfg(prev_sample=prev)
