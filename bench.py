@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
-    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "inversion_pair", "maskprop", "warp"])
+    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "inversion_pair", "maskprop", "warp", "sd3_transfer"])
     ap.add_argument("--model", default="sd15", choices=["sd15", "sd21"], help="UNet configuration: SD-v1.5 (headline) or the SD-v2.1 layout "
                                                                             "(Linear projections, head_dim 64, 1024-wide text states; SURVEY §8f-3)")
     ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
@@ -232,6 +232,89 @@ def run_aux_workload(a, dev):
     return out
 
 
+def sd3_step_flops(cfg, B, N, T, shift_window=False):
+    """algorithmic matrix flops of one MM-DiT forward on B frames of N image + T text tokens with the cross-frame key set
+    [first | prev | cur] ++ text (3N + T keys per query)."""
+    D, L = cfg.num_attention_heads * cfg.attention_head_dim, cfg.num_layers
+    nd = len(cfg.dual_attention_layers)
+    img_lin = L * (8 + 16) * D * D + nd * 8 * D * D                    # q,k,v,out + FF (4x) per image token; attn2 of the dual blocks
+    txt_lin = (L - 1) * (8 + 16) * D * D + 6 * D * D                   # last block: context_pre_only (no to_add_out, no ff_context)
+    attn = L * 4 * (N + T) * (3 * N + T) * D + nd * 4 * N * 3 * N * D
+    emb = 2 * N * (cfg.in_channels * cfg.patch_size ** 2) * D + 2 * N * D * cfg.patch_size ** 2 * cfg.out_channels + 2 * T * cfg.joint_attention_dim * D
+    return B * (N * img_lin + T * txt_lin + attn + emb)
+
+
+def run_sd3_workload(a, dev):
+    """BASELINE config 5 on ONE GPU: the three-branch transfer step of the SD3.5-medium MM-DiT (24 blocks, 1536 wide, 13 dual-attention
+    blocks) at 16 x 1024 x 1024 (4096 image + 333 text tokens per frame, batch 48), AttentionShiftProcessor registered, random-init
+    weights, synthetic latents / prompt embeddings.  A step = mask-free loop iteration: cat -> transformer -> eta-interpolated Euler."""
+    import types
+    from univst_amd import _native
+    from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+    from univst_amd.backbones.video_diffusion_sd3.models.transformer_3D_model import sd35_medium
+    from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
+    from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    F_, hl = a.frames, a.latent * 2 if a.latent == 64 else a.latent          # default --latent 64 is the SD-v1.5 size: 128 here (1024 px)
+    torch.manual_seed(33)
+    with torch.device(dev):
+        model = sd35_medium()
+    model = model.half().requires_grad_(False)
+    pipe = CustomStableDiffusion3Pipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler())
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    g = torch.Generator(device=dev).manual_seed(5)
+    rn = lambda *sh: torch.randn(*sh, generator=g, device=dev, dtype=torch.float16)          # noqa: E731
+    T = 77 + 256
+    pe, pp = rn(1, T, 4096).repeat(3 * F_, 1, 1), rn(1, 2048).repeat(3 * F_, 1)
+    content = [rn(F_, 16, hl, hl) for _ in range(4)]
+    style = [rn(F_, 16, hl, hl) for _ in range(4)]
+    target = rn(F_, 16, hl, hl)
+    ts, tl, ds = pipe._schedule(50)
+    eta = pipe.generate_eta_values(tl, 25, 39, 0.85, "constant")
+
+    def step(i, lat):
+        i = i % 50
+        c_t, s_t = content[i % 4], style[i % 4]
+        if i >= 40 and i <= 45:
+            lat = pnp_utils.latent_adain(lat, s_t)
+        x = torch.cat([c_t, s_t, lat])
+        v = model(hidden_states=x, timestep=ts[i].expand(3 * F_), encoder_hidden_states=pe, pooled_projections=pp, return_dict=False,
+                  joint_attention_kwargs={"idx": i})[0]
+        return pipe._euler_eta(lat, v[2 * F_:].contiguous(), target, ds[i], eta[i], tl[i] / 1000.0)
+
+    idx = [(j * 50) // a.steps if a.steps < 50 else j % 50 for j in range(a.steps)]
+    lat = rn(F_, 16, hl, hl)
+    for i in range(max(1, a.warmup)):
+        lat = step(idx[i % len(idx)], lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in idx:
+        lat = step(i, lat)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    assert torch.isfinite(lat.float()).all(), "non-finite latents"
+    N = (hl // 2) ** 2
+    fl = sd3_step_flops(model.config, 3 * F_, N, T)
+    out = {"metric": "stylized frames/sec, SD-v3.5-medium 16x1024x1024 @50 rectified-flow steps (three-branch transfer)", "value": round(F_ / (50 * ms / 1e3), 4),
+           "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": round(ms, 2), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic latents + prompt embeddings, random-init weights (2.2 B parameters)",
+           "config": {"workload": f"sd35_medium_mmdit_three_branch_transfer_{F_}x{hl * 8}x{hl * 8}_50rf", "frames": F_, "tokens_per_frame": N,
+                      "text_tokens": T, "batch": 3 * F_, "parallelism": "single",
+                      "note": "BASELINE config 5 names 8 GPUs and fp8 QKV; this is the single-GPU fp16 line (the reference's --weight_dtype default)"}}
+    tf = fl / (ms * 1e-3) / 1e12
+    out["roofline"] = {"bound": "mfma", "kernel": "whole step (linears + joint attention)", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(tf / PEAK_FP16_TFLOPS, 4), "traffic": None, "algorithmic_tflop_per_step": round(fl / 1e12, 2)}
+    if not a.no_profile:
+        _native.profile_enable(True)
+        lat2 = step(idx[0], lat)
+        torch.cuda.synchronize()
+        prof = _native.profile_collect()
+        _native.profile_enable(False)
+        del lat2
+        out["kernel_classes_ms"] = {k: round(v["ms"], 2) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:10]} if isinstance(prof, dict) else prof
+    out["cpu_baseline"] = None
+    return out
+
+
 def self_launch(a):
     """`python bench.py --gpus N` with no launcher environment: re-execute this command under torch.distributed.run with one rank per
     GPU (exactly what the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N` does), so the
@@ -300,11 +383,11 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local)
 
-    if a.workload in ("maskprop", "warp"):
-        assert world == 1, "maskprop / warp are sequential over frames: replicas only (DESIGN.md §5)"
+    if a.workload in ("maskprop", "warp", "sd3_transfer"):
+        assert world == 1, "maskprop / warp are sequential over frames (replicas only, DESIGN.md §5); sd3_transfer is a single-GPU line so far"
         from univst_amd import _native
         _native.load()
-        out = run_aux_workload(a, dev)
+        out = run_sd3_workload(a, dev) if a.workload == "sd3_transfer" else run_aux_workload(a, dev)
         print(json.dumps(out))
         return
 

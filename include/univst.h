@@ -120,6 +120,12 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value);
  * Replaces torch Linear / 1x1 conv call sites attention.py:123,141,375-377,425. */
 int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr,
                   void* Y, int64_t ldy, int M, int N, int K, int geglu, void* stream);
+/* The linear with the MM-DiT epilogues of the SD3 path (diffusers JointTransformerBlock / FeedForward, third-party):
+ *   Y = residual + gate[m / rows_per_gate] (.) act(X W^T + bias)
+ * act: UNIVST_ACT_NONE or UNIVST_ACT_GELU_TANH (defined below); gate (may be NULL): rows of N halfs, ld_gate apart, 16-byte aligned
+ * (a chunk of the adaLN linear's [B, 6C] output: rows_per_gate = tokens per frame); residual may be NULL. */
+int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr, void* Y, int64_t ldy,
+                        int M, int N, int K, int act, const void* gate, int64_t ld_gate, int rows_per_gate, void* stream);
 /* The same linear with a LayerNorm folded into it and / or row statistics emitted for the next one (what the UNet graph does with
  * norm1/2/3 of a transformer block, attention.py:311-329).  Only for problems the direct 256x320 tile takes (N % 320 == 0, at
  * least 150 tiles; else UNIVST_ERR_ARG).
@@ -183,9 +189,16 @@ typedef struct {
     const void *norm_added_q, *norm_added_k;
     const void *to_out, *to_out_bias, *to_add_out, *to_add_out_bias;                /* [Cin, heads*head_dim] */
 } univst_sd3_attn_weights;
+/* optional: the MM-DiT block's gated residuals fused into the two out-projections (diffusers JointTransformerBlock:
+ * hidden + gate_msa[:, None] * attn_output): out_img = res_img + gate_img[b] (.) to_out(o), out_txt likewise through to_add_out.
+ * gate_*: rows of Cin halfs, ld_gate_* apart (chunks of the two adaLN linears' outputs), one per frame b. */
+typedef struct {
+    const void *res_img, *gate_img, *res_txt, *gate_txt;
+    int64_t ld_gate_img, ld_gate_txt;
+} univst_sd3_gated_residual;
 int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin,
                                int heads, int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps,
-                               void* out_img, void* out_txt, void* stream);
+                               void* out_img, void* out_txt, const univst_sd3_gated_residual* gated_residual /* may be NULL */, void* stream);
 /* the shift alone, in place on a fused [3*F*N, 3C] q | k | v buffer (branch 0 content, 1 style, 2 stylised; row stride ld):
  * q2 <- gamma*(alpha*q0 + (1-alpha)*q2);  k2 <- beta*AdaIN(k2; k1) + (1-beta)*k1 (same for v) with the SD3 plugin's AdaIN
  * (pnp_utils.py:289-302: F.instance_norm over (N, head_dim) jointly per (frame, head), style mean / unbiased std per channel over N).
@@ -207,6 +220,7 @@ int univst_gate_residual(const void* x, const void* gate, int64_t ld_gate, const
  * (FeedForward activation_fn="gelu-approximate") */
 #define UNIVST_ACT_SILU 0
 #define UNIVST_ACT_GELU_TANH 1
+#define UNIVST_ACT_NONE (-1)
 int univst_activation(const void* x, void* out, int64_t n, int act, void* stream);
 /* diffusers Timesteps / get_timestep_embedding: t fp32 [B] (device) -> out fp16 [B, dim] = [sin | cos](t * freq) (halves swapped when
  * flip_sin_to_cos), freq_i = exp(-ln(max_period) i / (dim/2 - downscale_freq_shift)), fp32 arithmetic */

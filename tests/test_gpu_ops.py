@@ -92,6 +92,26 @@ def test_linear_big_tile_path(nat):
     close(nat.linear(x, w[idx].contiguous(), bias=b[idx].contiguous(), geglu=True), a * F.gelu(gate))
 
 
+def test_linear_big_tile_ragged_last_column_tile(nat):
+    """N not a multiple of 320 on the 256 x 320 tile (the MM-DiT widths of the SD3 path: 1536 = 4.8 tiles; also 648 = 2 tiles + 8
+    columns): weight rows >= N come from the zero page, both epilogues (LDS transpose with aligned rows, per-row otherwise) skip the
+    columns >= N, nothing is written past a row's N columns (canary columns in a wider output buffer)."""
+    for M, N, K, wide in ((40000 + 13, 1536, 192, 0), (50000, 648, 64, 0), (40000, 1536, 64, 1544)):
+        x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+        b, r = rnd(N, seed=3), rnd(M, N, seed=4)
+        ref = x.float() @ w.float().T + b.float() + r.float()
+        if not wide:
+            close(nat.linear(x, w, bias=b, residual=r), ref)
+            close(nat.linear(x, w), x.float() @ w.float().T)
+            continue
+        from univst_amd import _native
+        out = torch.full((M, wide), 7.0, device="cuda", dtype=torch.float16)
+        _native.check(_native.load().univst_linear(x.data_ptr(), K, w.data_ptr(), b.data_ptr(), r.data_ptr(), N, out.data_ptr(), wide, M, N, K, 0,
+                                                   _native.stream_ptr()), "linear")
+        close(out[:, :N], ref)
+        assert bool((out[:, N:] == 7.0).all()), "columns past N were written"
+
+
 def test_conv_big_tile_path(nat):
     imgs, C1, C2, Co, H = 48, 32, 16, 320, 56        # 150528 output rows -> 588 tiles of 256x320
     x1, x2 = rnd(imgs, C1, H, H, seed=1), rnd(imgs, C2, H, H, seed=2)

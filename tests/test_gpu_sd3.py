@@ -242,6 +242,43 @@ def test_sd3_transformer_univst_processors_vs_restatement(nat, idx):
     assert mx < 1e-2 and rms < 4e-3, (mx, rms)
 
 
+def test_linear_gated_epilogue_and_unfused_block_path(nat):
+    """Y = residual + gate[b] * gelu_tanh(X W^T + bias) on the small (128-row), split-K and 256 x 320 (ragged N) kernels against torch
+    fp32; and a block whose processor does NOT advertise the fused gated residual (a third-party processor) gives the same output
+    as the fused path."""
+    g = torch.Generator().manual_seed(21)
+    for B, N, K, Nout in ((3, 50, 64, 96), (2, 40, 2048, 64), (12, 4096, 64, 1536)):
+        x = torch.randn(B * N, K, generator=g).half().cuda()
+        w = (torch.randn(Nout, K, generator=g) / K ** 0.5).half().cuda()
+        b = (0.2 * torch.randn(Nout, generator=g)).half().cuda()
+        r = torch.randn(B * N, Nout, generator=g).half().cuda()
+        emb = torch.randn(B, 3 * Nout, generator=g).half().cuda()
+        gate = emb[:, Nout:2 * Nout]
+        lin = x.float() @ w.float().T + b.float()
+        for act, f in ((None, lambda v: v), (nat.ACT_GELU_TANH, lambda v: torch.nn.functional.gelu(v, approximate="tanh"))):
+            want = r.float() + gate.float().repeat_interleave(N, dim=0) * f(lin)
+            got = nat.linear_gated(x, w, b, residual=r, act=act, gate=gate, rows_per_gate=N)
+            mx, rms = errs(got, want)
+            assert mx < 3e-3 and rms < 6e-4, (B, N, K, Nout, act, mx, rms)
+        mx, _ = errs(nat.linear_gated(x, w, b, act=nat.ACT_GELU_TANH), torch.nn.functional.gelu(lin, approximate="tanh"))
+        assert mx < 3e-3, mx
+    m, _ = _tiny_sd3(layers=2, dual=(0,))
+    lat, enc, pooled, t = _sd3_inputs(6, 16, 7)
+    args = dict(hidden_states=lat.cuda(), timestep=t.cuda(), encoder_hidden_states=enc.cuda(), pooled_projections=pooled.cuda(), return_dict=False)
+    fused = m(**args)[0]
+
+    class Plain:                       # no supports_fused_gated_residual: the block applies gate_residual itself
+        def __init__(self, inner):
+            self.inner = inner
+
+        def __call__(self, attn, hidden_states, encoder_hidden_states=None, **kw):
+            return self.inner(attn, hidden_states, encoder_hidden_states=encoder_hidden_states, **kw)
+    m.set_attn_processor({n: Plain(p) for n, p in m.attn_processors.items()})
+    plain = m(**args)[0]
+    mx, rms = errs(plain, fused)
+    assert mx < 4e-3 and rms < 1e-3, (mx, rms)
+
+
 def test_sd3_elementwise_operators(nat):
     g = torch.Generator().manual_seed(3)
     x = (3 * torch.randn(5, 40, 64, generator=g)).half()

@@ -32,6 +32,11 @@ class Sd3AttnWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _NAMES]
 
 
+class Sd3GatedResidual(C.Structure):
+    _fields_ = [("res_img", C.c_void_p), ("gate_img", C.c_void_p), ("res_txt", C.c_void_p), ("gate_txt", C.c_void_p), ("ld_gate_img", C.c_int64),
+                ("ld_gate_txt", C.c_int64)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int)
 KVEXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
 
@@ -66,9 +71,11 @@ SIGNATURES = {
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P, _P]),
+    "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P,
+                                        C.POINTER(Sd3GatedResidual), _P]),
     "univst_sd3_adain_shift": (_I, [_P, _L, _I, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_rmsnorm_heads": (_I, [_P, _L, _L, _I, _I, _P, _F, _P]),
+    "univst_linear_gated": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _P]),
     "univst_adaln_modulate": (_I, [_P, _P, _P, _P, _L, _L, _L, _I, _F, _P, _P, _P, _P]),
     "univst_gate_residual": (_I, [_P, _P, _L, _P, _P, _L, _L, _I, _P]),
     "univst_activation": (_I, [_P, _P, _L, _I, _P]),
@@ -148,6 +155,18 @@ def linear(x, w, bias=None, residual=None, geglu=False, out=None):
         out = torch.empty(M, No, device=x.device, dtype=torch.float16)
     check(load().univst_linear(ptr(x), K, ptr(w), ptr(bias), ptr(residual), No, ptr(out), No, M, N, K, int(geglu),
                                stream_ptr()), "linear")
+    return out
+
+
+def linear_gated(x, w, bias=None, residual=None, act=None, gate=None, rows_per_gate=1, out=None):
+    """y[M,N] = residual + gate[m // rows_per_gate] * act(x w^T + bias); act None or ACT_GELU_TANH; gate a [B, N] row view."""
+    _f16(x), _f16(w)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float16)
+    check(load().univst_linear_gated(ptr(x), K, ptr(w), ptr(bias), ptr(residual), N, ptr(out), N, M, N, K, -1 if act is None else act,
+                                     ptr(gate), 0 if gate is None else _mod_ld(gate), rows_per_gate, stream_ptr()), "linear_gated")
     return out
 
 
@@ -252,10 +271,12 @@ _SD3_KEYS = {"to_q": "to_q.weight", "to_q_bias": "to_q.bias", "to_k": "to_k.weig
              "to_out": "to_out.0.weight", "to_out_bias": "to_out.0.bias", "to_add_out": "to_add_out.weight", "to_add_out_bias": "to_add_out.bias"}
 
 
-def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False, idx=-1, eta1=0.0, eta2=0.6, rms_eps=1e-6):
+def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False, idx=-1, eta1=0.0, eta2=0.6, rms_eps=1e-6, fuse=None):
     """CrossFrameProcessor / AttentionShiftProcessor of the reference's SD3 plugin on the native kernels.  params: the state dict
     of diffusers' Attention module (to_q.weight, ..., to_add_out.bias; missing entries = absent).  hidden [B, N, Cin],
-    enc [B, Nt, Cin] or None -> (img [B, N, Cin], txt [B, Nt, Cin]) or img alone."""
+    enc [B, Nt, Cin] or None -> (img [B, N, Cin], txt [B, Nt, Cin]) or img alone.  clip_length 0: no cross-frame keys.
+    fuse (optional): dict(res_img, gate_img[, res_txt, gate_txt]) — the block's gated residuals computed in the out-projections'
+    epilogue: the returned tensors are then res + gate[:, None] * attention output."""
     _f16(hidden)
     B, N, Cin = hidden.shape
     keep = {k: params[v].to(device=hidden.device, dtype=torch.float16).contiguous() for k, v in _SD3_KEYS.items() if params.get(v) is not None}
@@ -268,8 +289,14 @@ def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False,
         _f16(enc)
         Nt = enc.shape[1]
         out_t = torch.empty(B, Nt, Cin if "to_add_out" in keep else inner, device=hidden.device, dtype=torch.float16)
+    gr = None
+    if fuse is not None:
+        gt = fuse.get("gate_txt")
+        gr = Sd3GatedResidual(ptr(_f16(fuse["res_img"])), ptr(fuse["gate_img"]), ptr(fuse.get("res_txt")), ptr(gt), _mod_ld(fuse["gate_img"]),
+                              0 if gt is None else _mod_ld(gt))
     check(load().univst_sd3_joint_attention(C.byref(w), ptr(hidden), ptr(enc), B, N, Nt, Cin, heads, inner // heads, clip_length, int(bool(shift)),
-                                            int(idx), eta1, eta2, rms_eps, ptr(out_i), ptr(out_t), stream_ptr()), "sd3_joint_attention")
+                                            int(idx), eta1, eta2, rms_eps, ptr(out_i), ptr(out_t), C.byref(gr) if gr is not None else None,
+                                            stream_ptr()), "sd3_joint_attention")
     return (out_i, out_t) if enc is not None else out_i
 
 

@@ -77,12 +77,13 @@ class Attention(nn.Module):
 
 class JointAttnProcessor2_0:
     """diffusers' stock joint attention (no cross-frame keys): what the blocks run until a UniVST processor is registered."""
+    supports_fused_gated_residual = True
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, *args, **kwargs):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, *args, fused_gated_residual=None, **kwargs):
         from ..pnp_utils import _run
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the UniVST path")
-        return _run(attn, hidden_states, encoder_hidden_states, False, -1, 0.0, 0.0, clip_length=0)
+        return _run(attn, hidden_states, encoder_hidden_states, False, -1, 0.0, 0.0, clip_length=0, fuse=fused_gated_residual)
 
 
 class _AdaNorm(nn.Module):
@@ -106,11 +107,15 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([_GELU(dim, 4 * dim), nn.Identity(), nn.Linear(4 * dim, dim)])
 
-    def forward(self, x):
+    def forward(self, x, residual=None, gate=None):
+        """residual / gate (optional): returns residual + gate[:, None] * ff(x) from the second linear's epilogue; GELU(tanh) sits in the
+        first linear's epilogue — the 4x-wide intermediate is written once and read once."""
         B, N, D = x.shape
-        h = _linear(x.reshape(B * N, D), self.net[0].proj)
-        _native.activation(h, _native.ACT_GELU_TANH, out=h)
-        return _linear(h, self.net[2]).view(B, N, D)
+        w1, b1 = _w(self.net[0].proj)
+        w2, b2 = _w(self.net[2])
+        h = _native.linear_gated(x.reshape(B * N, D), w1, b1, act=_native.ACT_GELU_TANH)
+        res = None if residual is None else residual.reshape(B * N, D)
+        return _native.linear_gated(h, w2, b2, residual=res, gate=gate, rows_per_gate=N).view(B, N, D)
 
 
 class JointTransformerBlock(nn.Module):
@@ -139,18 +144,27 @@ class JointTransformerBlock(nn.Module):
             ne = _native.adaln_modulate(encoder_hidden_states, ch(cemb, 0), ch(cemb, 1), 1e-6)
         else:
             ne = _native.adaln_modulate(encoder_hidden_states, ch(cemb, 1), ch(cemb, 0), 1e-6)
-        a_img, a_txt = self.attn(hidden_states=nh, encoder_hidden_states=ne, **kw)
-        hidden_states = _native.gate_residual(hidden_states, ch(emb, 2), a_img)
+        fused = getattr(self.attn.processor, "supports_fused_gated_residual", False)
+        if fused:                                                   # hidden + gate_msa * attn (and the text stream's) in the out-projections' epilogue
+            fg = dict(res_img=hidden_states, gate_img=ch(emb, 2))
+            if not self.context_pre_only:
+                fg.update(res_txt=encoder_hidden_states, gate_txt=ch(cemb, 2))
+            hidden_states, enc = self.attn(hidden_states=nh, encoder_hidden_states=ne, fused_gated_residual=fg, **kw)
+        else:
+            a_img, a_txt = self.attn(hidden_states=nh, encoder_hidden_states=ne, **kw)
+            hidden_states = _native.gate_residual(hidden_states, ch(emb, 2), a_img)
+            enc = None if self.context_pre_only else _native.gate_residual(encoder_hidden_states, ch(cemb, 2), a_txt)
         if self.use_dual_attention:
-            a2 = self.attn2(hidden_states=nh2, **kw)
-            hidden_states = _native.gate_residual(hidden_states, ch(emb, 8), a2, out=hidden_states)
+            if getattr(self.attn2.processor, "supports_fused_gated_residual", False):
+                hidden_states = self.attn2(hidden_states=nh2, fused_gated_residual=dict(res_img=hidden_states, gate_img=ch(emb, 8)), **kw)
+            else:
+                hidden_states = _native.gate_residual(hidden_states, ch(emb, 8), self.attn2(hidden_states=nh2, **kw))
         n2 = _native.adaln_modulate(hidden_states, ch(emb, 4), ch(emb, 3), 1e-6)
-        hidden_states = _native.gate_residual(hidden_states, ch(emb, 5), self.ff(n2), out=hidden_states)
+        hidden_states = self.ff(n2, residual=hidden_states, gate=ch(emb, 5))
         if self.context_pre_only:
             return None, hidden_states
-        enc = _native.gate_residual(encoder_hidden_states, ch(cemb, 2), a_txt)
         n2c = _native.adaln_modulate(enc, ch(cemb, 4), ch(cemb, 3), 1e-6)
-        enc = _native.gate_residual(enc, ch(cemb, 5), self.ff_context(n2c), out=enc)
+        enc = self.ff_context(n2c, residual=enc, gate=ch(cemb, 5))
         return enc, hidden_states
 
 

@@ -18,7 +18,7 @@ def _params(attn):
     return {k: v for k, v in attn.state_dict().items()}
 
 
-def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2, clip_length=16):
+def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2, clip_length=16, fuse=None):
     dt, dev = hidden_states.dtype, hidden_states.device
     if dev.type != "cuda":
         raise RuntimeError("univst_amd SD3 processors run on the GPU only (no CPU path): move the tensors to cuda")
@@ -26,32 +26,37 @@ def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2, cli
     enc = None if encoder_hidden_states is None else encoder_hidden_states.to(torch.float16).contiguous()
     eps = getattr(getattr(attn, "norm_q", None), "eps", None) or 1e-6
     out = _native.sd3_joint_attention(_params(attn), hid, enc, attn.heads, clip_length=clip_length, shift=shift, idx=idx, eta1=eta1, eta2=eta2,
-                                      rms_eps=float(eps))
+                                      rms_eps=float(eps), fuse=fuse)
     if enc is None:
         return out.to(dt)
     return out[0].to(dt), out[1].to(dt)
 
 
 class CrossFrameProcessor:
-    """pnp_utils.py:9-131: joint attention whose image keys / values are those of frames ['first', f-1, f] of the clip."""
+    """pnp_utils.py:9-131: joint attention whose image keys / values are those of frames ['first', f-1, f] of the clip.
+    ``fused_gated_residual`` (addition, keyword only): the native MM-DiT block hands its gated residual to processors that
+    advertise ``supports_fused_gated_residual``; the result is then hidden + gate * attention output (one epilogue, no extra pass)."""
+    supports_fused_gated_residual = True
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, **kwargs):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, fused_gated_residual=None, **kwargs):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the UniVST path")
-        return _run(attn, hidden_states, encoder_hidden_states, False, idx, 0.0, 0.0)
+        return _run(attn, hidden_states, encoder_hidden_states, False, idx, 0.0, 0.0, fuse=fused_gated_residual)
 
 
 class AttentionShiftProcessor:
     """pnp_utils.py:134-271: the same with the AdaIN-guided shift of the stylised branch inside eta1*50 <= idx <= eta2*50."""
 
+    supports_fused_gated_residual = True
+
     def __init__(self, eta1, eta2):
         self.eta1, self.eta2 = eta1, eta2
         self.thresh2 = eta2          # the attribute the reference forgets to set (see the module docstring)
 
-    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, **kwargs):
+    def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, fused_gated_residual=None, **kwargs):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the UniVST path")
-        return _run(attn, hidden_states, encoder_hidden_states, True, idx, self.eta1, self.thresh2)
+        return _run(attn, hidden_states, encoder_hidden_states, True, idx, self.eta1, self.thresh2, fuse=fused_gated_residual)
 
 
 def register_spatial_attention_pnp(model, eta1=0.0, eta2=0.6):

@@ -107,6 +107,17 @@ int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, c
     g.M = M; g.N = N; g.K = K; g.geglu = geglu;
     return uv_launch_gemm(g, 0, S(s));
 }
+int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                        int M, int N, int K, int act, const void* gate, int64_t ld_gate, int rows_per_gate, void* s) {
+    UV_REQUIRE(X && W && Y, "linear_gated: null argument");
+    UV_REQUIRE(act == UNIVST_ACT_NONE || act == UNIVST_ACT_GELU_TANH, "linear_gated: act must be UNIVST_ACT_NONE or UNIVST_ACT_GELU_TANH");
+    GemmParams g;
+    g.X = H(X); g.ldx = ldx; g.W = H(W); g.bias = H(bias); g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy;
+    g.M = M; g.N = N; g.K = K;
+    g.act = act == UNIVST_ACT_GELU_TANH ? 1 : 0;
+    g.gate = H(gate); g.ld_gate = ld_gate; g.rows_per_gate = gate ? rows_per_gate : 1;
+    return uv_launch_gemm(g, 0, S(s));
+}
 int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                      int M, int N, int K, int geglu, const float* ln_stats, float ln_eps, const float* ln_wsum, const float* ln_bias,
                      float* stats_out, void* s) {

@@ -69,6 +69,12 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 // exact (erf) GELU with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below fp16 resolution): one
 // rcp + one exp2 + 8 fma/mul instead of the ~40-instruction libm erff — the GEGLU epilogue runs it 250 M times per
 // layer.  gelu(x) = 0.5*x*(1 + erf(x/sqrt2)) = 0.5*(x + |x| * erf(|x|/sqrt2))  (erf is odd), so no sign select.
+// GELU(tanh) of torch (approximate="tanh"): 0.5 x (1 + tanh(u)) = x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3): one exp2 + one rcp
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -2.8853900817779268f));
+}
+
 __device__ __forceinline__ float gelu_erf_f(float x) {
     const float ax = fabsf(x);
     const float z = ax * 0.70710678118654752f;

@@ -154,6 +154,17 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (float)bv[r];
             }
+            if constexpr (LNF == 3) {          // MM-DiT epilogue (own instantiation: the plain kernels keep their register budget)
+                if (p.act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                }
+                if (p.gate) {
+                    const h4 gv = *reinterpret_cast<const h4*>(p.gate + (long)(m / p.rows_per_gate) * p.ld_gate + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= (float)gv[r];
+                }
+            }
             if (p.R) {
                 const h4 rv = hres[i];
 #pragma unroll
@@ -176,6 +187,10 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                 float t = v[r];
                 if (p.bias) t += (float)p.bias[n + r];
                 if (rbias) t += (float)rbias[n + r];
+                if constexpr (LNF == 3) {
+                    if (p.act) t = gelu_tanh_f(t);
+                    if (p.gate) t *= (float)p.gate[(long)(m / p.rows_per_gate) * p.ld_gate + n + r];
+                }
                 if (p.R) t += (float)p.R[(long)m * p.ldr + n + r];
                 half_t o = (half_t)t;
                 if (p.bias2) o = (half_t)((float)o + (float)p.bias2[n + r]);
@@ -220,7 +235,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     const int row = id / 20, c = (id - row * 20) * 8;
                     const int m = mrow0 + row < p.M ? mrow0 + row : p.M - 1;
                     const half_t* src = p.R ? p.R + (long)m * p.ldr : p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N);
-                    rres[it] = *reinterpret_cast<const h8*>(src + nb + c);
+                    rres[it] = nb + c < p.N ? *reinterpret_cast<const h8*>(src + nb + c) : h8{0, 0, 0, 0, 0, 0, 0, 0};      // ragged last column tile
                 }
             }
 #pragma unroll
@@ -230,7 +245,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                 const int m = mrow0 + row, n = nb + c;
                 const f4 v0 = *reinterpret_cast<const f4*>(&slab[row * EPI_LDW + c]);
                 const f4 v1 = *reinterpret_cast<const f4*>(&slab[row * EPI_LDW + c + 4]);
-                if (m >= p.M) continue;
+                if (m >= p.M || n >= p.N) continue;            // (n >= N: the ragged last column tile of a linear whose N is not a multiple of 320)
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 if (LNF == 2) {
                     const float2 ln = reinterpret_cast<const float2*>(cf + EPC_ROWST)[rw + j * 16 + row];
@@ -250,6 +265,17 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     const h8 bv = hoist_rb ? rres[it] : *reinterpret_cast<const h8*>(p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) + n);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
+                }
+                if constexpr (LNF == 3) {
+                    if (p.act) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_f(v[r]);
+                    }
+                    if (p.gate) {
+                        const h8 gv = *reinterpret_cast<const h8*>(p.gate + (long)(m / p.rows_per_gate) * p.ld_gate + n);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= (float)gv[r];
+                    }
                 }
                 if (p.R) {
                     const h8 rv = rres[it];
@@ -504,7 +530,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         f4 col[NF];
 #pragma unroll
         for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
-        gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MF + j * 16 + l15, n0 + wn * NF * 16, g);
+        if (p.act || p.gate) gemm_epilogue_row<NF, 3>(p, col, m0 + wm * 16 * MF + j * 16 + l15, n0 + wn * NF * 16, g);
+        else gemm_epilogue_row<NF>(p, col, m0 + wm * 16 * MF + j * 16 + l15, n0 + wn * NF * 16, g);
     }
 }
 
@@ -517,7 +544,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     f4 a = *reinterpret_cast<const f4*>(p.partial + (long)m * p.N + n);
     for (int sidx = 1; sidx < p.splits; ++sidx) a += *reinterpret_cast<const f4*>(p.partial + ((long)sidx * p.M + m) * p.N + n);
     f4 col[1] = {a};
-    gemm_epilogue_row<1>(p, col, m, n, 0);
+    if (p.act || p.gate) gemm_epilogue_row<1, 3>(p, col, m, n, 0);
+    else gemm_epilogue_row<1>(p, col, m, n, 0);
 }
 
 
@@ -527,7 +555,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 // operand traffic per flop is 2.2x lower than the 128x128 kernel, which is what lifts the L2-bandwidth ceiling
 // those tiles sit on.  Staging is global_load_lds only (two 72 KB LDS buffers, unpadded 128 B
 // rows, XOR-swizzled chunks), one barrier per 64-wide k tile, 80 MFMAs per wave between barriers.
-// LNF: 0 plain, 1 emits the row statistics of its output (GemmParams::stats_out), 2 folds a LayerNorm of its input (ln_stats)
+// LNF: 0 plain, 1 emits the row statistics of its output (GemmParams::stats_out), 2 folds a LayerNorm of its input (ln_stats),
+// 3 the MM-DiT epilogue (GemmParams::act / gate)
 template <int MODE, int MJ, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     // MJ = 16-row fragments per wave along M: 4 -> 256-row tile, 3 -> 192-row tile (same kernel, chosen per problem so that
@@ -1004,8 +1033,11 @@ static const BigEnv& big_env() {
                              (getenv("UNIVST_GEMM_BIGMIN") && atol(getenv("UNIVST_GEMM_BIGMIN"))) ? atol(getenv("UNIVST_GEMM_BIGMIN")) : 150};   // measured cross-over (tools/bench_gemm_mid.py)
     return e;
 }
-static bool big_shape_ok(int N, int K, long x_elems) {      // x_elems: extent of the activation operand in elements (32-bit DMA offsets)
-    return !big_env().nobig && N % 320 == 0 && (long)N * K < (1L << 31) && x_elems < (1L << 31);
+// ragged: a plain linear (no GEGLU, no LayerNorm fold / statistics, no split-K) may end in a partly filled column tile (N % 8 == 0):
+// the MM-DiT widths of the SD3 path (1536, 4608, 6144 = 4.8 / 14.4 / 19.2 tiles) lose 4 % of the MFMA work to padding and still run
+// 1.4x faster than on the 128 x 128 tile.  Weight rows >= N come from the zero page; both epilogues skip columns >= N.
+static bool big_shape_ok(int N, int K, long x_elems, bool ragged = false) {      // x_elems: extent of the activation operand in elements (32-bit DMA offsets)
+    return !big_env().nobig && (N % 320 == 0 || (ragged && N % 8 == 0 && N >= 640)) && (long)N * K < (1L << 31) && x_elems < (1L << 31);
 }
 
 // Does a plain linear [M, K] (row stride ldx, 0 = K) x [N, K]^T take the direct (no split-K) 256x320 path whose epilogue can fold a
@@ -1021,6 +1053,9 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     const bool lnf = p.ln_stats || p.stats_out;
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
+    UV_REQUIRE(!(p.act || p.gate) || (!p.geglu && !lnf && mode == 0), "gemm: the activation / gate epilogue is for plain linears (no GEGLU, LayerNorm fold, conv)");
+    UV_REQUIRE(!p.gate || (p.rows_per_gate >= 1 && p.ld_gate % 8 == 0 && p.N % 8 == 0 && (reinterpret_cast<uintptr_t>(p.gate) & 15) == 0),
+               "gemm: gate rows must be 16-byte aligned (ld_gate %% 8 == 0, N %% 8 == 0)");
     if (mode == 0) {
         UV_REQUIRE(p.ldx % 8 == 0, "gemm: ldx=%ld must be a multiple of 8", p.ldx);
     } else {
@@ -1035,10 +1070,14 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         // rounds but 512 tiles of 192 = 2 exact ones; 12288 x 1280 is 192 vs 256 tiles)
         static const int bm_env = getenv("UNIVST_GEMM_BM") ? atoi(getenv("UNIVST_GEMM_BM")) : 0;     // A/B aid: force 256 / 192
         const long ncu = uv_num_cus();
-        const long n256 = (long)((p.M + 255) / 256) * (p.N / 320), n192 = (long)((p.M + 191) / 192) * (p.N / 320);
+        const bool ragged = mode == 0 && !p.geglu && !lnf;
+        const int ntn_c = (p.N + 319) / 320;
+        const long n256 = (long)((p.M + 255) / 256) * ntn_c, n192 = (long)((p.M + 191) / 192) * ntn_c;
         // per-row cost of the 192-row tile relative to the 256-row one, measured at equal round counts: convs 0.96-1.0, linears 1.02-1.07
         const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * (mode == 1 ? 0.99 : 1.05);
-        const bool use192 = bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150);
+        // (the MM-DiT epilogue instantiation fits the 256-VGPR budget only with the 192-row tile: 223 registers; 256 rows spill 48)
+        const bool mmdit_epi = mode == 0 && (p.act || p.gate);
+        const bool use192 = mmdit_epi ? true : (bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150));
         const long nblk = use192 ? n192 : n256;
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
         const long bigmin = big_env().bigmin;
@@ -1055,7 +1094,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         const bool use_patch = patch_env && mode == 1 && (nblk >= bigmin || bsplits > 1) && uv_conv_patch_eligible(p, use192 ? 192 : 256);
         UV_REQUIRE(p.W || use_patch, "conv: only the [Cin/32][9][32] weight copy was given but the problem is not eligible for the LDS-patch kernel "
                    "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles or a reduction long enough for split-K)");
-        if (big_shape_ok(p.N, p.K, xmax) && (nblk >= bigmin || bsplits > 1)) {
+        if (big_shape_ok(p.N, p.K, xmax, ragged) && (nblk >= bigmin || bsplits > 1)) {
             uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K,
                           2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
             // row-contiguous epilogue through LDS needs 16-byte aligned rows everywhere it touches; it pays for the plain
@@ -1065,7 +1104,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             GemmParams q = p;
             {   // row-group x column-block tile order for wide outputs (see gemm_big_kernel); UNIVST_GEMM_TILEORDER=0: column-fastest
                 static const int to_env = getenv("UNIVST_GEMM_TILEORDER") ? atoi(getenv("UNIVST_GEMM_TILEORDER")) : 1;
-                const int ntn = p.N / 320;
+                const int ntn = ntn_c;
                 q.tile_gn = 0;
                 if (to_env && mode == 0 && ntn > 4 && (long)p.N * p.K * 2 > (3L << 20)) {      // W larger than ~3 MB: it cannot stay in L2 as a whole
                     q.tile_gn = ntn % 2 == 0 ? 2 : 0;       // 8 x 2 measured best of 8x4 / 16x2 / 4x8 / 16x4 / 32x4 (all within 2 %); 10 x 3 was a loss
@@ -1124,6 +1163,8 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                     if (use192) hipLaunchKernelGGL((gemm_big_kernel<0, 3, 1>), bgrid, dim3(512), 0, stream, q);
                     else hipLaunchKernelGGL((gemm_big_kernel<0, 4, 1>), bgrid, dim3(512), 0, stream, q);
                 }
+            } else if (mmdit_epi) {                            // MM-DiT epilogue: GELU(tanh) / gate (.) + residual
+                hipLaunchKernelGGL((gemm_big_kernel<0, 3, 3>), bgrid, dim3(512), 0, stream, q);
             } else if (use192) {
                 if (mode == 0) hipLaunchKernelGGL((gemm_big_kernel<0, 3>), bgrid, dim3(512), 0, stream, q);
                 else hipLaunchKernelGGL((gemm_big_kernel<1, 3>), bgrid, dim3(512), 0, stream, q);

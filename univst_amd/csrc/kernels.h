@@ -26,6 +26,11 @@ struct GemmParams {
     long ldr = 0;
     const half_t* bias2 = nullptr;     // second bias added after fp16 rounding (attn_temporal bias)
     int geglu = 0;                     // W rows interleaved [16 x | 16 gate]; writes N/2 columns x*gelu(gate)
+    // MM-DiT epilogues (SD3 path; not with geglu / the LayerNorm fold): Y = R + gate[m / rows_per_gate] (.) act(acc + bias + rowbias)
+    int act = 0;                       // 1: GELU(tanh)  (FeedForward activation_fn="gelu-approximate")
+    const half_t* gate = nullptr;      // [M / rows_per_gate] rows of N gate values, ld_gate halfs apart (a chunk of the adaLN linear's output)
+    long ld_gate = 0;
+    int rows_per_gate = 1;
     int epi_lds = 0;                   // 256x320 kernel: transpose the tile through LDS for row-contiguous stores
     // split-K (small M*N, long K: the deep UNet levels, and every level of a frame shard): grid = tiles x splits, each block
     // reduces ktps k tiles into fp32 partials [splits][M][N]; a second kernel sums them in split order and applies the epilogue.

@@ -45,6 +45,58 @@ __global__ __launch_bounds__(256) void rms_heads_kernel(half_t* __restrict__ x, 
     }
 }
 
+// the same for head widths of 8 * 2^k (32, 64, 128): LPH = d / 8 lanes share a head, 16 bytes per lane, the reduction is
+// log2(LPH) shuffles; one pass serves BOTH the q and the k columns of a fused q | k | v row (column blocks c0 and c1, own weights;
+// c1 < 0: one block).  HBM-bound: 2 x 2 x rows x heads x d bytes per call.
+template <int LPH>
+__global__ __launch_bounds__(256) void rms_heads_vec_kernel(half_t* __restrict__ x, long ld, long rows, int heads, long c0, long c1,
+                                                            const half_t* __restrict__ w0, const half_t* __restrict__ w1, float eps) {
+    constexpr int D = LPH * 8;
+    const long per_row = (long)heads * LPH;                       // 16-byte pieces per row and column block
+    const long nblk = c1 >= 0 ? 2 : 1;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row * nblk) return;                       // (whole heads sit inside a wave: 64 % LPH == 0, per_row % LPH == 0)
+    const long r = i / (per_row * nblk);
+    const long q = i - r * per_row * nblk;
+    const int blk = (int)(q / per_row);
+    const long piece = q - blk * per_row;
+    const int e0 = (int)(piece % LPH) * 8;
+    half_t* ptr = x + r * ld + (blk ? c1 : c0) + piece * 8;
+    const h8 v = *reinterpret_cast<const h8*>(ptr);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+#pragma unroll
+    for (int o = 1; o < LPH; o <<= 1) ss += __shfl_xor(ss, o, 64);
+    const float r_ = rsqrtf(ss / D + eps);
+    const h8 wv = *reinterpret_cast<const h8*>((blk ? w1 : w0) + e0);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)v[e] * r_ * (float)wv[e]);
+    *reinterpret_cast<h8*>(ptr) = o;
+}
+
+// launcher: q and k of a fused buffer in one pass when the head width allows (w1 / c1 optional)
+static int launch_rms_pair(half_t* x, long ld, long rows, int heads, int d, long c0, const half_t* w0, long c1, const half_t* w1, float eps,
+                           hipStream_t s) {
+    const bool two = w1 != nullptr;
+    const bool vec = (d == 32 || d == 64 || d == 128) && ld % 8 == 0 && c0 % 8 == 0 && (!two || c1 % 8 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w0) | reinterpret_cast<uintptr_t>(w1)) & 15) == 0;
+    if (vec) {
+        const long n = rows * heads * (d / 8) * (two ? 2 : 1);
+        const dim3 grid((unsigned)((n + 255) / 256));
+        const long cc1 = two ? c1 : -1;
+        if (d == 32) hipLaunchKernelGGL(rms_heads_vec_kernel<4>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps);
+        else if (d == 64) hipLaunchKernelGGL(rms_heads_vec_kernel<8>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps);
+        else hipLaunchKernelGGL(rms_heads_vec_kernel<16>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps);
+    } else {
+        hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, s, x + c0, ld, rows, heads, d, w0, eps);
+        if (two) hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, s, x + c1, ld, rows, heads, d, w1, eps);
+    }
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
 // per (frame, t in {K, V}, head): (mu, rstd) of the stylised branch over (N, d) jointly, from its per-column statistics
 // (colstats: mean_c, unbiased std_c over the N rows): sum_n x^2 = (N-1) std_c^2 + N mean_c^2
 __global__ void sd3_group_stats_kernel(const float* __restrict__ mean, const float* __restrict__ stdv, int F, int N, int C, int heads,
@@ -94,20 +146,36 @@ __global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv
     }
 }
 
-// src_idx [B][3] = ['first', f-1 (clipped), f] of the frame's own clip, x_idx [B] = the frame itself (pnp_utils.py:27,53-78)
-// clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): src_idx [B][1] = the frame itself
-__global__ void sd3_index_kernel(int B, int clip, int* __restrict__ src_idx, int* __restrict__ x_idx) {
+// src_idx [B][3] = ['first', f-1 (clipped), f] of the frame's own clip, x_idx [B] = the frame itself (pnp_utils.py:27,53-78), with
+// duplicate sources merged as on the SD-v1.5 path (frame 0 of a clip reads itself three times, frame 1 reads frame 0 twice): a source
+// that occurs c times is listed once with log2-weight log2(c) — softmax over duplicated keys == softmax with the key's exp weighted c.
+// clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): the frame itself, once
+__global__ void sd3_index_kernel(int B, int clip, int* __restrict__ src_idx, int* __restrict__ x_idx, int* __restrict__ cnt,
+                                 float* __restrict__ logw) {
     const int bf = blockIdx.x * blockDim.x + threadIdx.x;
     if (bf >= B) return;
     x_idx[bf] = bf;
+    int* si = src_idx + bf * 3;
+    float* lw = logw + bf * 3;
+    si[0] = si[1] = si[2] = bf;
+    lw[0] = lw[1] = lw[2] = 0.f;
     if (clip == 0) {
-        src_idx[bf] = bf;
+        cnt[bf] = 1;
         return;
     }
     const int b = bf / clip, f = bf - b * clip;
-    src_idx[bf * 3 + 0] = b * clip;
-    src_idx[bf * 3 + 1] = b * clip + (f > 0 ? f - 1 : 0);
-    src_idx[bf * 3 + 2] = bf;
+    if (f == 0) {
+        cnt[bf] = 1;
+        lw[0] = 1.5849625007211562f;          // log2(3)
+    } else if (f == 1) {
+        cnt[bf] = 2;
+        si[0] = b * clip;
+        lw[0] = 1.f;                          // log2(2): 'first' and f-1 are the same frame
+    } else {
+        cnt[bf] = 3;
+        si[0] = b * clip;
+        si[1] = bf - 1;
+    }
 }
 
 // y = LN(x) * (1 + scale[b]) + shift[b] (and optionally y2 with a second (scale2, shift2) from the SAME normalised row:
@@ -240,9 +308,11 @@ __global__ void axpbypcz_kernel(const half_t* __restrict__ x, const half_t* __re
     if (i < n) out[i] = (half_t)(a * (float)x[i] + b * (float)y[i] + c * (float)z[i]);
 }
 
-int linear(const half_t* X, long ldx, long M, int K, const half_t* W, const half_t* b, int N, half_t* Y, long ldy, hipStream_t s) {
+int linear(const half_t* X, long ldx, long M, int K, const half_t* W, const half_t* b, int N, half_t* Y, long ldy, hipStream_t s,
+           const half_t* res = nullptr, const half_t* gate = nullptr, long ld_gate = 0, int rows_per_gate = 1) {
     GemmParams g;
     g.X = X; g.ldx = ldx; g.M = (int)M; g.K = K; g.N = N; g.W = W; g.bias = b; g.Y = Y; g.ldy = ldy;
+    g.R = res; g.ldr = N; g.gate = gate; g.ld_gate = ld_gate; g.rows_per_gate = rows_per_gate;      // Y = res + gate[b] (.) (X W^T + b)
     return uv_launch_gemm(g, 0, s);
 }
 
@@ -258,10 +328,7 @@ extern "C" {
 
 int univst_rmsnorm_heads(void* x, int64_t ld, int64_t rows, int heads, int d, const void* weight, float eps, void* stream) {
     UV_REQUIRE(x && weight && rows >= 1 && heads >= 1 && d >= 1 && d <= 256, "rmsnorm_heads: bad argument (head_dim <= 256)");
-    hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (half_t*)x, ld, rows, heads, d,
-                       (const half_t*)weight, eps);
-    UV_LAUNCH_CHECK();
-    return UV_OK;
+    return launch_rms_pair((half_t*)x, ld, rows, heads, d, 0, (const half_t*)weight, 0, nullptr, eps, (hipStream_t)stream);
 }
 
 int univst_adaln_modulate(const void* x, void* y, const void* scale, const void* shift, int64_t ld_mod, int64_t rows, int64_t rows_per_batch,
@@ -352,7 +419,7 @@ int univst_sd3_adain_shift(void* qkv, int64_t ld, int F, int N, int C, int heads
 
 int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin, int heads,
                                int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps, void* out_img,
-                               void* out_txt, void* stream) {
+                               void* out_txt, const univst_sd3_gated_residual* gr, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     UV_REQUIRE(w && hidden && out_img && B >= 1 && N >= 1 && heads >= 1, "sd3_joint_attention: null / empty argument");
     UV_REQUIRE(w->to_q && w->to_k && w->to_v && w->to_out, "sd3_joint_attention: to_q / to_k / to_v / to_out weights are required");
@@ -360,6 +427,8 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
                B, clip_length);
     UV_REQUIRE(!shift || B % 3 == 0, "sd3_joint_attention: the attention shift needs the three-branch batch");
     UV_REQUIRE(!enc || (out_txt && Nt >= 1 && w->add_q && w->add_k && w->add_v), "sd3_joint_attention: text tokens need add_{q,k,v}_proj and out_txt");
+    UV_REQUIRE(!gr || (gr->res_img && gr->gate_img && (!enc || !w->to_add_out || (gr->res_txt && gr->gate_txt))),
+               "sd3_joint_attention: a gated residual needs residual and gate pointers for every projected stream");
     const int C = heads * head_dim;
     UV_REQUIRE(Cin % 8 == 0 && C % 8 == 0, "sd3_joint_attention: widths must be multiples of 8");
     const long rows_i = (long)B * N, rows_t = enc ? (long)B * Nt : 0;
@@ -368,7 +437,7 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
     const size_t n_half = (size_t)(rows_i + rows_t) * 4 * C;
     const size_t n_stat = shift ? (size_t)4 * Fb * 2 * C + (size_t)2 * Fb * 2 * heads : 0;
     char* ws = nullptr;
-    const size_t bytes = n_half * sizeof(half_t) + n_stat * sizeof(float) + (size_t)B * 4 * sizeof(int) + 1024;
+    const size_t bytes = n_half * sizeof(half_t) + n_stat * sizeof(float) + (size_t)B * 8 * sizeof(int) + 1024;      // src_idx[3B] x_idx[B] cnt[B] logw[3B]
     UV_HIP(hipMallocAsync((void**)&ws, bytes, s));
     half_t* qkv_i = (half_t*)ws;
     half_t* qkv_t = qkv_i + rows_i * 3 * C;
@@ -383,8 +452,9 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         RUN(linear(x, Cin, rows_i, Cin, H(w->to_q), H(w->to_q_bias), C, qkv_i, 3 * C, s));
         RUN(linear(x, Cin, rows_i, Cin, H(w->to_k), H(w->to_k_bias), C, qkv_i + C, 3 * C, s));
         RUN(linear(x, Cin, rows_i, Cin, H(w->to_v), H(w->to_v_bias), C, qkv_i + 2 * C, 3 * C, s));
-        if (w->norm_q) RUN(univst_rmsnorm_heads(qkv_i, 3 * C, rows_i, heads, head_dim, w->norm_q, rms_eps, s));
-        if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
+        if (w->norm_q && w->norm_k) RUN(launch_rms_pair(qkv_i, 3 * C, rows_i, heads, head_dim, 0, H(w->norm_q), C, H(w->norm_k), rms_eps, s));
+        else if (w->norm_q) RUN(univst_rmsnorm_heads(qkv_i, 3 * C, rows_i, heads, head_dim, w->norm_q, rms_eps, s));
+        else if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
         if (shift && (float)idx >= eta1 * 50.f && (float)idx <= eta2 * 50.f) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0)
             const float beta = (0.9f - 0.1f) / (eta1 * 50.f - eta2 * 50.f) * ((float)idx - eta2 * 50.f) + 0.1f;
             RUN(univst_sd3_adain_shift(qkv_i, 3 * C, Fb, N, C, heads, 0.8f, beta, 2.0f, st, s));
@@ -394,23 +464,30 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             RUN(linear(e, Cin, rows_t, Cin, H(w->add_q), H(w->add_q_bias), C, qkv_t, 3 * C, s));
             RUN(linear(e, Cin, rows_t, Cin, H(w->add_k), H(w->add_k_bias), C, qkv_t + C, 3 * C, s));
             RUN(linear(e, Cin, rows_t, Cin, H(w->add_v), H(w->add_v_bias), C, qkv_t + 2 * C, 3 * C, s));
-            if (w->norm_added_q) RUN(univst_rmsnorm_heads(qkv_t, 3 * C, rows_t, heads, head_dim, w->norm_added_q, rms_eps, s));
-            if (w->norm_added_k) RUN(univst_rmsnorm_heads(qkv_t + C, 3 * C, rows_t, heads, head_dim, w->norm_added_k, rms_eps, s));
+            if (w->norm_added_q && w->norm_added_k)
+                RUN(launch_rms_pair(qkv_t, 3 * C, rows_t, heads, head_dim, 0, H(w->norm_added_q), C, H(w->norm_added_k), rms_eps, s));
+            else if (w->norm_added_q) RUN(univst_rmsnorm_heads(qkv_t, 3 * C, rows_t, heads, head_dim, w->norm_added_q, rms_eps, s));
+            else if (w->norm_added_k) RUN(univst_rmsnorm_heads(qkv_t + C, 3 * C, rows_t, heads, head_dim, w->norm_added_k, rms_eps, s));
         }
-        hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, tab, tab + 3 * B);
+        hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, tab, tab + 3 * B, tab + 4 * B,
+                           (float*)(tab + 5 * B));
         UV_LAUNCH_CHECK();
         AttnParams a;
         a.k = qkv_i + C; a.v = qkv_i + 2 * C; a.ldkv = 3 * C;
-        a.src_idx = tab; a.nsrc = clip_length ? 3 : 1; a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
+        a.src_idx = tab; a.nsrc = 3; a.src_cnt = tab + 4 * B; a.src_logw = (const float*)(tab + 5 * B); a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
         a.scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
         if (enc) { a.kx = qkv_t + C; a.vx = qkv_t + 2 * C; a.ldkv_x = 3 * C; a.Nkv_x = Nt; a.x_idx = tab + 3 * B; }
         a.q = qkv_i; a.ldq = 3 * C; a.Nq = N; a.o = o_i; a.ldo = C;
         RUN(uv_launch_attention(a, s));                                  // image queries over [first | prev | cur] ++ text keys
-        RUN(linear(o_i, C, rows_i, C, H(w->to_out), H(w->to_out_bias), Cin, (half_t*)out_img, Cin, s));
+        // (gr: the block's gated residual rides in the out-projection's epilogue: out = res + gate[b] (.) to_out(o))
+        RUN(linear(o_i, C, rows_i, C, H(w->to_out), H(w->to_out_bias), Cin, (half_t*)out_img, Cin, s, gr ? H(gr->res_img) : nullptr,
+                   gr ? H(gr->gate_img) : nullptr, gr ? gr->ld_gate_img : 0, N));
         if (enc) {
             a.q = qkv_t; a.Nq = Nt; a.o = o_t;
             RUN(uv_launch_attention(a, s));                              // text queries over the same key set
-            if (w->to_add_out) RUN(linear(o_t, C, rows_t, C, H(w->to_add_out), H(w->to_add_out_bias), Cin, (half_t*)out_txt, Cin, s));
+            if (w->to_add_out)
+                RUN(linear(o_t, C, rows_t, C, H(w->to_add_out), H(w->to_add_out_bias), Cin, (half_t*)out_txt, Cin, s, gr ? H(gr->res_txt) : nullptr,
+                           gr ? H(gr->gate_txt) : nullptr, gr ? gr->ld_gate_txt : 0, Nt));
             else UV_HIP(hipMemcpyAsync(out_txt, o_t, (size_t)rows_t * C * sizeof(half_t), hipMemcpyDeviceToDevice, s));      // context_pre_only
         }
         return UV_OK;
