@@ -23,6 +23,11 @@ python bench.py --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_em
 python bench.py --frames 32 --no-cpu-baseline --no-skip-dead-branches-leg > $O/round${ROUND}_bench_f32_n1.json 2>> $O/raw/bench.err
 python bench.py --model sd21 --no-cpu-baseline > $O/round${ROUND}_bench_sd21_n1.json 2>> $O/raw/bench.err
 [ "${FULLCPU:-1}" = 1 ] && python bench.py --full-cpu --no-profile --no-skip-dead-branches-leg > $O/round${ROUND}_bench_fullcpu.json 2>> $O/raw/bench.err
+python bench.py --workload sd3_transfer --steps 5 --warmup 1 > $O/round${ROUND}_bench_sd3_transfer.json 2>> $O/raw/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats_sd3 -- python bench.py --workload sd3_transfer --steps 3 --warmup 1 --no-profile > $O/raw/sd3_rocprof.log 2>&1
+cp $(ls $O/raw/stats_sd3/*/*kernel_stats.csv | head -1) $O/round${ROUND}_kernel_stats_sd3_transfer.csv
+# two ranks on this ONE GPU through the library's IPC communicator: evidence that the multi-rank path executes end to end (not a scaling number)
+python bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_two_ranks_one_gpu.json 2>> $O/raw/bench.err
 tools/probes/coissue_probe > $O/round${ROUND}_coissue_probe.txt 2>&1
 tools/probes/ipc_probe 1 > $O/round${ROUND}_ipc_probe.txt 2>&1
 ROUND=$ROUND python tools/summarize_profiles.py $O
