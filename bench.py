@@ -244,8 +244,9 @@ def sd3_step_flops(cfg, B, N, T, shift_window=False):
     return B * (N * img_lin + T * txt_lin + attn + emb)
 
 
-def run_sd3_workload(a, dev):
-    """BASELINE config 5 on ONE GPU: the three-branch transfer step of the SD3.5-medium MM-DiT (24 blocks, 1536 wide, 13 dual-attention
+def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
+    """BASELINE config 5 (one GPU, or frame-sharded over `world` ranks: K/V of the clip's first and of the previous frame travel
+    through the library's IPC communicator inside every joint attention): the three-branch transfer step of the SD3.5-medium MM-DiT (24 blocks, 1536 wide, 13 dual-attention
     blocks) at 16 x 1024 x 1024 (4096 image + 333 text tokens per frame, batch 48), AttentionShiftProcessor registered, random-init
     weights, synthetic latents / prompt embeddings.  A step = mask-free loop iteration: cat -> transformer -> eta-interpolated Euler."""
     import types
@@ -254,14 +255,18 @@ def run_sd3_workload(a, dev):
     from univst_amd.backbones.video_diffusion_sd3.models.transformer_3D_model import sd35_medium
     from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
     from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
-    F_, hl = a.frames, a.latent * 2 if a.latent == 64 else a.latent          # default --latent 64 is the SD-v1.5 size: 128 here (1024 px)
+    from univst_amd.parallel import Sd3FrameShard
+    F_all, hl = a.frames, a.latent * 2 if a.latent == 64 else a.latent       # default --latent 64 is the SD-v1.5 size: 128 here (1024 px)
+    shard = Sd3FrameShard(rank, world, F_all)
+    F_ = shard.local
     torch.manual_seed(33)
     with torch.device(dev):
         model = sd35_medium()
     model = model.half().requires_grad_(False)
     pipe = CustomStableDiffusion3Pipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler())
     pnp_utils.register_spatial_attention_pnp(pipe)
-    g = torch.Generator(device=dev).manual_seed(5)
+    shard.attach(model, tokens=(hl // 2) ** 2)
+    g = torch.Generator(device=dev).manual_seed(5 + rank)
     rn = lambda *sh: torch.randn(*sh, generator=g, device=dev, dtype=torch.float16)          # noqa: E731
     T = 77 + 256
     pe, pp = rn(1, T, 4096).repeat(3 * F_, 1, 1), rn(1, 2048).repeat(3 * F_, 1)
@@ -281,29 +286,41 @@ def run_sd3_workload(a, dev):
                   joint_attention_kwargs={"idx": i})[0]
         return pipe._euler_eta(lat, v[2 * F_:].contiguous(), target, ds[i], eta[i], tl[i] / 1000.0)
 
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     idx = [(j * 50) // a.steps if a.steps < 50 else j % 50 for j in range(a.steps)]
     lat = rn(F_, 16, hl, hl)
     for i in range(max(1, a.warmup)):
         lat = step(idx[i % len(idx)], lat)
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in idx:
         lat = step(i, lat)
-    torch.cuda.synchronize()
+    sync()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    if dist is not None:                      # MAX over ranks
+        outs = [None] * world
+        dist.all_gather_object(outs, ms)
+        ms = max(outs)
     assert torch.isfinite(lat.float()).all(), "non-finite latents"
     N = (hl // 2) ** 2
+    F_ = F_all
     fl = sd3_step_flops(model.config, 3 * F_, N, T)
-    out = {"metric": "stylized frames/sec, SD-v3.5-medium 16x1024x1024 @50 rectified-flow steps (three-branch transfer)", "value": round(F_ / (50 * ms / 1e3), 4),
-           "unit": "frames/s", "n_gpus": 1, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": round(ms, 2), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic latents + prompt embeddings, random-init weights (2.2 B parameters)",
+    out = {"metric": f"stylized frames/sec, SD-v3.5-medium {F_}x{hl * 8}x{hl * 8} @50 rectified-flow steps (three-branch transfer)",
+           "value": round(F_ / (50 * ms / 1e3), 4),
+           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": round(ms, 2), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic latents + prompt embeddings, random-init weights (2.2 B parameters)",
            "config": {"workload": f"sd35_medium_mmdit_three_branch_transfer_{F_}x{hl * 8}x{hl * 8}_50rf", "frames": F_, "tokens_per_frame": N,
-                      "text_tokens": T, "batch": 3 * F_, "parallelism": "single",
-                      "note": "BASELINE config 5 names 8 GPUs and fp8 QKV; this is the single-GPU fp16 line (the reference's --weight_dtype default)"}}
-    tf = fl / (ms * 1e-3) / 1e12
-    out["roofline"] = {"bound": "mfma", "kernel": "whole step (linears + joint attention)", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-                       "frac": round(tf / PEAK_FP16_TFLOPS, 4), "traffic": None, "algorithmic_tflop_per_step": round(fl / 1e12, 2)}
-    if not a.no_profile:
+                      "text_tokens": T, "batch": 3 * F_, "parallelism": "single" if world == 1 else f"frames{world} (IPC communicator)",
+                      "note": "BASELINE config 5 names 8 GPUs and fp8 QKV; fp16 here (the reference's --weight_dtype default); --gpus N shards the frames"}}
+    tf = fl / (ms * 1e-3) / 1e12 / world
+    out["roofline"] = {"bound": "mfma", "kernel": "whole step (linears + joint attention), per GPU", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS,
+                       "unit": "TFLOP/s", "frac": round(tf / PEAK_FP16_TFLOPS, 4), "traffic": None, "algorithmic_tflop_per_step": round(fl / 1e12, 2)}
+    if not a.no_profile and world == 1:
         _native.profile_enable(True)
         lat2 = step(idx[0], lat)
         torch.cuda.synchronize()
@@ -384,11 +401,15 @@ def main():
     dev = torch.device("cuda", local)
 
     if a.workload in ("maskprop", "warp", "sd3_transfer"):
-        assert world == 1, "maskprop / warp are sequential over frames (replicas only, DESIGN.md §5); sd3_transfer is a single-GPU line so far"
+        assert world == 1 or a.workload == "sd3_transfer", "maskprop / warp are sequential over frames: replicas only (DESIGN.md §5)"
         from univst_amd import _native
         _native.load()
-        out = run_sd3_workload(a, dev) if a.workload == "sd3_transfer" else run_aux_workload(a, dev)
-        print(json.dumps(out))
+        out = run_sd3_workload(a, dev, rank, world, dist) if a.workload == "sd3_transfer" else run_aux_workload(a, dev)
+        if rank == 0:
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
 
     from univst_amd import _native, synth

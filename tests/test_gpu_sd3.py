@@ -453,3 +453,87 @@ def test_sd3_end_to_end_chain_through_files(nat, tmp_path):
                                     content_inv_path=str(out["c_inv"]), style_inv_path=str(out["s_inv"]), mask_path=None, eta_base=0.85,
                                     eta_trend="constant", start_step=25, end_step=39, output_type="latent").images
     assert lat.shape == (Fr, 16, 8, 8) and torch.isfinite(lat).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# frame shard of the SD3 path: two PROCESSES on this box's one GPU (as the SD-v1.5 shard is tested), the library's IPC communicator
+# carrying K | V of the clip's first frame and of the previous frame inside univst_sd3_joint_attention
+def _sd3_shard_rank(rank, world, port, q):
+    import os
+    import traceback
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+        from univst_amd.parallel import Sd3FrameShard
+        m, _ = _tiny_sd3(layers=2, dual=(0,))
+        pnp_utils.register_spatial_attention_pnp(types.SimpleNamespace(transformer=m), eta1=0.0, eta2=0.6)
+        lat, enc, pooled, t = _sd3_inputs(48, 8, 5, seed=9)
+        sh = Sd3FrameShard(rank, world, 16).attach(m, tokens=16)
+        out = {}
+        for idx in (10, 45, 11):                      # inside / outside the shift window; three consecutive exchanges (parity reuse)
+            v = m(hidden_states=sh.slice_branches(lat).cuda(), timestep=t.cuda().expand(3 * sh.local), encoder_hidden_states=sh.slice_branches(enc).cuda(),
+                  pooled_projections=sh.slice_branches(pooled).cuda(), return_dict=False, joint_attention_kwargs={"idx": idx})[0]
+            out[idx] = torch.stack([sh.gather_frames(c) for c in v.chunk(3)]).cpu()      # [branch, F, C, h, w]: every rank ends with all frames
+        torch.cuda.synchronize()
+        q.put((rank, {k: v.float().numpy() for k, v in out.items()}, None))      # by value: a tensor would travel as an fd of a process that may be gone
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_sd3_frame_shard_two_processes_ipc(nat):
+    import socket
+    import torch.multiprocessing as mp
+    from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+    m, _ = _tiny_sd3(layers=2, dual=(0,))
+    pnp_utils.register_spatial_attention_pnp(types.SimpleNamespace(transformer=m), eta1=0.0, eta2=0.6)
+    lat, enc, pooled, t = _sd3_inputs(48, 8, 5, seed=9)
+    ref = {}
+    for idx in (10, 45, 11):
+        v = m(hidden_states=lat.cuda(), timestep=t.cuda().expand(48), encoder_hidden_states=enc.cuda(), pooled_projections=pooled.cuda(),
+              return_dict=False, joint_attention_kwargs={"idx": idx})[0]
+        ref[idx] = torch.stack(list(v.chunk(3))).cpu()
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    world = 2
+    procs = [mpc.Process(target=_sd3_shard_rank, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = {}
+    for _ in range(world):
+        rank, out, err = q.get(timeout=600)
+        assert err is None, err
+        res[rank] = out
+    for pr in procs:
+        pr.join(timeout=120)
+    for r in range(world):
+        for idx in ref:
+            mx, rms = errs(torch.from_numpy(res[r][idx]), ref[idx])
+            assert mx < 4e-3 and rms < 1e-3, (r, idx, mx, rms)
+
+
+def test_bench_sd3_two_ranks_end_to_end():
+    """`python bench.py --workload sd3_transfer --gpus 2`: bench.py spawns its two ranks, both share this box's GPU (gloo process group for
+    the rendezvous), the frame-sharded MM-DiT step runs through the IPC communicator and rank 0 prints ONE JSON line with n_gpus = 2
+    (full SD3.5-medium weights, small clip: timing of two ranks on one GPU means nothing)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "sd3_transfer", "--gpus", "2", "--backend", "gloo", "--frames", "4",
+                        "--latent", "16", "--steps", "2", "--warmup", "1", "--no-profile"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["parallelism"].startswith("frames2") and d["scaling"] == "strong"

@@ -72,7 +72,7 @@ SIGNATURES = {
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P,
-                                        C.POINTER(Sd3GatedResidual), _P]),
+                                        C.POINTER(Sd3GatedResidual), _P, _P]),
     "univst_sd3_adain_shift": (_I, [_P, _L, _I, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_rmsnorm_heads": (_I, [_P, _L, _L, _I, _I, _P, _F, _P]),
     "univst_linear_gated": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _I, _P]),
@@ -271,12 +271,13 @@ _SD3_KEYS = {"to_q": "to_q.weight", "to_q_bias": "to_q.bias", "to_k": "to_k.weig
              "to_out": "to_out.0.weight", "to_out_bias": "to_out.0.bias", "to_add_out": "to_add_out.weight", "to_add_out_bias": "to_add_out.bias"}
 
 
-def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False, idx=-1, eta1=0.0, eta2=0.6, rms_eps=1e-6, fuse=None):
+def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False, idx=-1, eta1=0.0, eta2=0.6, rms_eps=1e-6, fuse=None, comm=None):
     """CrossFrameProcessor / AttentionShiftProcessor of the reference's SD3 plugin on the native kernels.  params: the state dict
     of diffusers' Attention module (to_q.weight, ..., to_add_out.bias; missing entries = absent).  hidden [B, N, Cin],
     enc [B, Nt, Cin] or None -> (img [B, N, Cin], txt [B, Nt, Cin]) or img alone.  clip_length 0: no cross-frame keys.
     fuse (optional): dict(res_img, gate_img[, res_txt, gate_txt]) — the block's gated residuals computed in the out-projections'
-    epilogue: the returned tensors are then res + gate[:, None] * attention output."""
+    epilogue: the returned tensors are then res + gate[:, None] * attention output.
+    comm (optional): pointer of a connected univst_comm — the batch is this rank's clip_length frames of every branch (frame shard)."""
     _f16(hidden)
     B, N, Cin = hidden.shape
     keep = {k: params[v].to(device=hidden.device, dtype=torch.float16).contiguous() for k, v in _SD3_KEYS.items() if params.get(v) is not None}
@@ -296,7 +297,7 @@ def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False,
                               0 if gt is None else _mod_ld(gt))
     check(load().univst_sd3_joint_attention(C.byref(w), ptr(hidden), ptr(enc), B, N, Nt, Cin, heads, inner // heads, clip_length, int(bool(shift)),
                                             int(idx), eta1, eta2, rms_eps, ptr(out_i), ptr(out_t), C.byref(gr) if gr is not None else None,
-                                            stream_ptr()), "sd3_joint_attention")
+                                            comm, stream_ptr()), "sd3_joint_attention")
     return (out_i, out_t) if enc is not None else out_i
 
 

@@ -25,8 +25,14 @@ def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2, cli
     hid = hidden_states.to(torch.float16).contiguous()
     enc = None if encoder_hidden_states is None else encoder_hidden_states.to(torch.float16).contiguous()
     eps = getattr(getattr(attn, "norm_q", None), "eps", None) or 1e-6
+    comm = None
+    shard = getattr(attn, "_uv_frame_shard", None)            # univst_amd.parallel.Sd3FrameShard.attach: this rank's frames of every branch
+    if shard is not None and shard.world > 1:
+        if clip_length == 0:
+            raise RuntimeError("a frame-sharded MM-DiT needs the cross-frame processors (CrossFrameProcessor / AttentionShiftProcessor)")
+        clip_length, comm = shard.local, shard.comm.ptr
     out = _native.sd3_joint_attention(_params(attn), hid, enc, attn.heads, clip_length=clip_length, shift=shift, idx=idx, eta1=eta1, eta2=eta2,
-                                      rms_eps=float(eps), fuse=fuse)
+                                      rms_eps=float(eps), fuse=fuse, comm=comm)
     if enc is None:
         return out.to(dt)
     return out[0].to(dt), out[1].to(dt)

@@ -278,6 +278,24 @@ int uv_unet_attach_comm(UNet& u, univst_comm* c) {
     u.native_comm = c;
     return UV_OK;
 }
+// ---- SD3 side (csrc/sd3.hip): the same K/V exchange with explicit offsets, plus a one-float all-reduce used as a barrier — the
+// MM-DiT has no GroupNorm all-reduces between two consecutive exchanges, and it is those that keep a fast rank from overwriting an
+// inbox its neighbour has not unpacked yet (see the reuse argument at the top of this file)
+int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s) {
+    UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
+    UV_REQUIRE(o_send >= 0 && o_first >= 0 && o_prev >= 0 && o_rfirst >= 0 && nbytes > 0 &&
+               (o_send > o_first ? o_send : o_first) + nbytes <= c->ws_bytes && (o_prev > o_rfirst ? o_prev : o_rfirst) + nbytes <= c->ws_bytes,
+               "kv_exchange: a %ld-byte pack does not fit the communicator's %ld-byte workspace", nbytes, c->ws_bytes);
+    c->stream = s;
+    return comm_kv_cb(c, o_send, o_first, o_prev, o_rfirst, nbytes);
+}
+int uv_comm_barrier(univst_comm* c, hipStream_t s) {             // (the first 64 KiB of the workspace are the all-reduce scratch of both paths)
+    return uv_comm_allreduce(c, reinterpret_cast<float*>(c->mine + UV_OFF_WS), 1, s);
+}
+char* uv_comm_ws(univst_comm* c) { return c->mine + UV_OFF_WS; }
+long uv_comm_ws_bytes(const univst_comm* c) { return c->ws_bytes; }
+int uv_comm_rank(const univst_comm* c) { return c->rank; }
+int uv_comm_world(const univst_comm* c) { return c->world; }
 void uv_comm_bind_stream(univst_comm* c, hipStream_t s) { c->stream = s; }
 unsigned uv_comm_kv_parity(const univst_comm* c) { return (c->kv_epoch + 1) & 1; }
 int uv_comm_poll(univst_comm* c) { return comm_check(c); }

@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "unet.h"
 #include "../../include/univst.h"
 
 namespace {
@@ -149,8 +150,10 @@ __global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv
 // src_idx [B][3] = ['first', f-1 (clipped), f] of the frame's own clip, x_idx [B] = the frame itself (pnp_utils.py:27,53-78), with
 // duplicate sources merged as on the SD-v1.5 path (frame 0 of a clip reads itself three times, frame 1 reads frame 0 twice): a source
 // that occurs c times is listed once with log2-weight log2(c) — softmax over duplicated keys == softmax with the key's exp weighted c.
-// clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): the frame itself, once
-__global__ void sd3_index_kernel(int B, int clip, int* __restrict__ src_idx, int* __restrict__ x_idx, int* __restrict__ cnt,
+// clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): the frame itself, once.
+// Frame shard (world > 1): this rank holds frames [rank*clip, (rank+1)*clip) of every branch; the clip's first frame and the frame
+// before this rank's first one arrive in the row blocks B + 2b (first) and B + 2b + 1 (previous) of branch b.
+__global__ void sd3_index_kernel(int B, int clip, int rank, int* __restrict__ src_idx, int* __restrict__ x_idx, int* __restrict__ cnt,
                                  float* __restrict__ logw) {
     const int bf = blockIdx.x * blockDim.x + threadIdx.x;
     if (bf >= B) return;
@@ -164,18 +167,31 @@ __global__ void sd3_index_kernel(int B, int clip, int* __restrict__ src_idx, int
         return;
     }
     const int b = bf / clip, f = bf - b * clip;
-    if (f == 0) {
+    const int gf = rank * clip + f;                                   // frame index in the whole clip
+    const int first = rank == 0 ? b * clip : B + 2 * b;               // row block holding the clip's first frame
+    const int prev = f > 0 ? bf - 1 : B + 2 * b + 1;                  // (gf >= 1) row block of frame gf - 1
+    if (gf == 0) {
         cnt[bf] = 1;
         lw[0] = 1.5849625007211562f;          // log2(3)
-    } else if (f == 1) {
+    } else if (gf == 1) {
         cnt[bf] = 2;
-        si[0] = b * clip;
-        lw[0] = 1.f;                          // log2(2): 'first' and f-1 are the same frame
+        si[0] = first;
+        lw[0] = 1.f;                          // log2(2): 'first' and gf - 1 are the same frame
     } else {
         cnt[bf] = 3;
-        si[0] = b * clip;
-        si[1] = bf - 1;
+        si[0] = first;
+        si[1] = prev;
     }
+}
+
+// rows x cols8 16-byte pieces between two row-strided matrices: packs / unpacks the k | v columns of one frame
+__global__ __launch_bounds__(256) void sd3_copy2d_kernel(const half_t* __restrict__ src, long ld_src, half_t* __restrict__ dst, long ld_dst,
+                                                         long rows, int cols8) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols8) return;
+    const long r = i / cols8;
+    const int c = (int)(i - r * cols8) * 8;
+    *reinterpret_cast<h8*>(dst + r * ld_dst + c) = *reinterpret_cast<const h8*>(src + r * ld_src + c);
 }
 
 // y = LN(x) * (1 + scale[b]) + shift[b] (and optionally y2 with a second (scale2, shift2) from the SAME normalised row:
@@ -419,7 +435,7 @@ int univst_sd3_adain_shift(void* qkv, int64_t ld, int F, int N, int C, int heads
 
 int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin, int heads,
                                int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps, void* out_img,
-                               void* out_txt, const univst_sd3_gated_residual* gr, void* stream) {
+                               void* out_txt, const univst_sd3_gated_residual* gr, univst_comm* comm, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     UV_REQUIRE(w && hidden && out_img && B >= 1 && N >= 1 && heads >= 1, "sd3_joint_attention: null / empty argument");
     UV_REQUIRE(w->to_q && w->to_k && w->to_v && w->to_out, "sd3_joint_attention: to_q / to_k / to_v / to_out weights are required");
@@ -431,16 +447,21 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
                "sd3_joint_attention: a gated residual needs residual and gate pointers for every projected stream");
     const int C = heads * head_dim;
     UV_REQUIRE(Cin % 8 == 0 && C % 8 == 0, "sd3_joint_attention: widths must be multiples of 8");
+    const int world = comm ? uv_comm_world(comm) : 1, rank = comm ? uv_comm_rank(comm) : 0;
+    const bool sharded = world > 1;
+    UV_REQUIRE(!sharded || clip_length >= 1, "sd3_joint_attention: a frame shard needs the cross-frame processors (clip_length = frames per rank)");
+    const int nbr = clip_length ? B / clip_length : 0;                 // branches (clips) in the batch
     const long rows_i = (long)B * N, rows_t = enc ? (long)B * Nt : 0;
+    const long rows_x = sharded ? (long)2 * nbr * N : 0;               // halo row blocks behind the local frames: (first, previous) per branch
     // one stream-ordered scratch block: qkv_img [rows_i, 3C] | qkv_txt [rows_t, 3C] | o_img [rows_i, C] | o_txt [rows_t, C] | stats | index tables
     const int Fb = B / 3;                                    // frames per branch (shift only)
-    const size_t n_half = (size_t)(rows_i + rows_t) * 4 * C;
+    const size_t n_half = (size_t)(rows_i + rows_t) * 4 * C + (size_t)rows_x * 3 * C;
     const size_t n_stat = shift ? (size_t)4 * Fb * 2 * C + (size_t)2 * Fb * 2 * heads : 0;
     char* ws = nullptr;
     const size_t bytes = n_half * sizeof(half_t) + n_stat * sizeof(float) + (size_t)B * 8 * sizeof(int) + 1024;      // src_idx[3B] x_idx[B] cnt[B] logw[3B]
     UV_HIP(hipMallocAsync((void**)&ws, bytes, s));
     half_t* qkv_i = (half_t*)ws;
-    half_t* qkv_t = qkv_i + rows_i * 3 * C;
+    half_t* qkv_t = qkv_i + (rows_i + rows_x) * 3 * C;
     half_t* o_i = qkv_t + rows_t * 3 * C;
     half_t* o_t = o_i + rows_i * C;
     float* st = (float*)(((uintptr_t)(o_t + rows_t * C) + 255) & ~(uintptr_t)255);
@@ -469,7 +490,40 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             else if (w->norm_added_q) RUN(univst_rmsnorm_heads(qkv_t, 3 * C, rows_t, heads, head_dim, w->norm_added_q, rms_eps, s));
             else if (w->norm_added_k) RUN(univst_rmsnorm_heads(qkv_t + C, 3 * C, rows_t, heads, head_dim, w->norm_added_k, rms_eps, s));
         }
-        hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, tab, tab + 3 * B, tab + 4 * B,
+        if (sharded) {
+            // K | V of this rank's last frame of every branch -> rank + 1, of the clip's first frame (rank 0) -> every rank; after the
+            // AdaIN shift, which rewrites the stylised branch's K / V.  Pack [branch][N][2C] in the communicator's workspace: 64 KiB of
+            // all-reduce scratch, then send | first | inbox[parity][previous, first].
+            const long pack = (((long)nbr * N * 2 * C * (long)sizeof(half_t)) + 255) & ~255L;
+            UV_REQUIRE(65536 + 6 * pack <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
+                       "6 K/V packs of %ld bytes", uv_comm_ws_bytes(comm), pack);
+            char* ws_c = uv_comm_ws(comm);
+            const long o_send = 65536, o_first = 65536 + pack;
+            const unsigned par = uv_comm_kv_parity(comm);
+            const long o_prev = 65536 + (2 + 2 * par) * pack, o_rfirst = o_prev + pack;
+            const long cpn = (long)N * (2 * C / 8);
+            const unsigned cgrid = (unsigned)((cpn + 255) / 256);
+            for (int b = 0; b < nbr; ++b) {
+                const half_t* last = qkv_i + ((long)(b * clip_length + clip_length - 1) * N) * 3 * C + C;
+                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, last, (long)3 * C, (half_t*)(ws_c + o_send) + (long)b * N * 2 * C,
+                                   (long)2 * C, (long)N, 2 * C / 8);
+                if (rank == 0)
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, qkv_i + ((long)b * clip_length * N) * 3 * C + C, (long)3 * C,
+                                       (half_t*)(ws_c + o_first) + (long)b * N * 2 * C, (long)2 * C, (long)N, 2 * C / 8);
+            }
+            RUN(uv_comm_kv_exchange(comm, o_send, o_first, o_prev, o_rfirst, (long)nbr * N * 2 * C * (long)sizeof(half_t), s));
+            if (rank > 0) {
+                for (int b = 0; b < nbr; ++b) {
+                    half_t* xf = qkv_i + (rows_i + (long)(2 * b) * N) * 3 * C + C;
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_rfirst) + (long)b * N * 2 * C, (long)2 * C,
+                                       xf, (long)3 * C, (long)N, 2 * C / 8);
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_prev) + (long)b * N * 2 * C, (long)2 * C,
+                                       xf + (long)N * 3 * C, (long)3 * C, (long)N, 2 * C / 8);
+                }
+            }
+            RUN(uv_comm_barrier(comm, s));        // nobody starts the next exchange before every rank has unpacked this one
+        }
+        hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, rank, tab, tab + 3 * B, tab + 4 * B,
                            (float*)(tab + 5 * B));
         UV_LAUNCH_CHECK();
         AttnParams a;

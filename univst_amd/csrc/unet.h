@@ -15,6 +15,12 @@ void uv_comm_bind_stream(univst_comm* c, hipStream_t s);
 unsigned uv_comm_kv_parity(const univst_comm* c);
 int uv_comm_poll(univst_comm* c);
 int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s);
+int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
+int uv_comm_barrier(univst_comm* c, hipStream_t s);
+char* uv_comm_ws(univst_comm* c);
+long uv_comm_ws_bytes(const univst_comm* c);
+int uv_comm_rank(const univst_comm* c);
+int uv_comm_world(const univst_comm* c);
 
 struct WTensor {
     half_t* ptr = nullptr;

@@ -180,6 +180,51 @@ class FrameShard:
         return step
 
 
+class Sd3FrameShard:
+    """Frame shard of the SD3 / SD3.5 path: frames are the batch axis there ([F, C, h, w] per branch), rank r holds frames
+    [r*F/W, (r+1)*F/W) of every branch, and the only coupling is the cross-frame key set of the joint attention — K | V of the clip's
+    first frame and of the previous frame, exchanged inside ``univst_sd3_joint_attention`` through the library's communicator
+    (csrc/comm.hip: peer writes + flags; one exchange and one barrier per attention layer).  AdaIN statistics, the latent AdaIN and
+    the Euler step are per frame: local.  IPC communicator only (one node)."""
+
+    def __init__(self, rank: int, world: int, frames: int, comm=None):
+        if frames % world:
+            raise ValueError(f"{frames} frames do not split over {world} ranks")
+        self.rank, self.world, self.frames = rank, world, frames
+        self.local = frames // world
+        self.f0 = rank * self.local
+        self.comm = comm
+
+    def slice_frames(self, t: torch.Tensor) -> torch.Tensor:
+        return t[self.f0:self.f0 + self.local].contiguous()
+
+    def slice_branches(self, t: torch.Tensor, branches: int = 3) -> torch.Tensor:
+        """[branches*F, ...] -> this rank's frames of every branch, [branches*F/W, ...]"""
+        return torch.cat([self.slice_frames(c) for c in t.chunk(branches)])
+
+    def attach(self, model, tokens: int, branches: int = 3):
+        """model: the native CustomSD3Transformer2DModel; tokens: image tokens per frame (sizes the K/V packs)."""
+        if self.world == 1:
+            return self
+        inner = model.inner_dim
+        pack = (branches * tokens * 2 * inner * 2 + 255) // 256 * 256
+        need = 65536 + 6 * pack + 4096
+        if self.comm is None:
+            self.comm = NativeIpcComm(self.rank, self.world, need, device=model.device)
+        else:
+            self.comm.ensure_bytes(need)
+        for blk in model.transformer_blocks:
+            blk.attn._uv_frame_shard = self
+            if blk.attn2 is not None:
+                blk.attn2._uv_frame_shard = self
+        return self
+
+    def gather_frames(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world == 1:
+            return t
+        return torch.cat(self.comm.all_gather(t.contiguous()), dim=0)
+
+
 # ------------------------------------------------------------------------------------------------ communicators
 class NativeIpcComm:
     """The library's own communicator (include/univst.h ``univst_comm_*``, csrc/comm.hip): device-side peer writes + flags through
