@@ -475,6 +475,45 @@ def test_attention_d40_long_merged_sources_and_text(nat):
     close(nat.attention(qxp, kt, vt, src, heads, ldkv=2 * C, Nkv=77, C_=C, q_prescaled=True), sdpa_ref(qxref, kt, vt, heads), rtol=4e-3)
 
 
+# ---- the software-pipelined head_dim-64 kernel (prescaled q, Nq >= 1024): reference in the MFMA accumulator, dot2 row sums --------
+def test_attention_d64_long_reference_jumps(nat):
+    """the d = 40 kernel's torture cases at head_dim 64 (attn_pp64_kernel): late large positive excursions, strongly negative first
+    scores, ragged key count; the same inputs with plain q (generic body) for comparison."""
+    heads, d, N = 2, 64, 1024 + 200
+    C = heads * d
+    q, k, v = rnd(1, N, C, seed=1) * 2, rnd(1, N, C, seed=2), rnd(1, N, C, seed=3)
+    k[0, 900] = q[0, 5] * 6
+    k[0, 70] = q[0, 9] * 5
+    k[0, 1200] = q[0, 1000] * 4          # inside the tail tile
+    q[0, 300] = -k[0, :64].mean(0) * 30
+    k[0, :32] = k[0, 3]
+    q[0, 400] = -k[0, 3] * 16
+    src = torch.zeros(1, 1, dtype=torch.int32).cuda()
+    qp, qref = prescaled(q, d)
+    close(nat.attention(qp, k, v, src, heads, q_prescaled=True), sdpa_ref(qref, k, v, heads), rtol=4e-3)
+    close(nat.attention(q, k, v, src, heads), sdpa_ref(q, k, v, heads), rtol=4e-3)
+
+
+def test_attention_d64_long_merged_sources(nat):
+    heads, d, N = 4, 64, 1088
+    C = heads * d
+    qkv = rnd(3, N, 3 * C, seed=1)
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    qp, qref = prescaled(q, d)
+    qkv[..., :C] = qp
+    dup = torch.tensor([[0, 0, 0], [0, 1, 0], [1, 2, 0]], dtype=torch.int32).cuda()
+    kk = torch.stack([torch.cat([k[j] for j in row]) for row in dup.tolist()]).float()
+    vv = torch.stack([torch.cat([v[j] for j in row]) for row in dup.tolist()]).float()
+    ref = sdpa_ref(qref.contiguous(), kk, vv, heads)
+    cnt = torch.tensor([1, 2, 3], dtype=torch.int32).cuda()
+    lw = torch.tensor([[math.log2(3), 0, 0], [1.0, 0, 0], [0, 0, 0]], dtype=torch.float32).cuda()
+    got = nat.attention(q, k, v, dup, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, src_cnt=cnt, src_logw=lw, q_prescaled=True)
+    close(got, ref, rtol=4e-3)
+    # un-merged (three explicit sources) gives the same
+    got2 = nat.attention(q, k, v, dup, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, q_prescaled=True)
+    close(got2, ref, rtol=4e-3)
+
+
 @pytest.mark.parametrize("C,N,Fr,idx", [(64, 64, 4, 0), (320, 256, 3, 13), (1280, 64, 2, 25)])
 def test_attention_adain_shift(nat, C, N, Fr, idx):
     qkv = (rnd(3 * Fr * N, 3 * C, seed=1) * 1.5 + 0.2)

@@ -242,6 +242,31 @@ def test_sd3_transformer_univst_processors_vs_restatement(nat, idx):
     assert mx < 1e-2 and rms < 4e-3, (mx, rms)
 
 
+def test_sd3_joint_attention_long_tokens_pipelined_kernel(nat):
+    """1100 image + 77 text tokens per frame (ragged tails in both segments), head_dim 64, q / k RMSNorm: the image queries take the
+    software-pipelined head_dim-64 kernel (prescaled q out of the norm, text tokens as the extra key segment, merged duplicate
+    sources), the text queries the generic body — against the G16/G18-pinned oracle, inside the shift window."""
+    g = torch.Generator().manual_seed(31)
+    heads, dh, N, Nt, F_ = 2, 64, 1100, 77, 3
+    C = heads * dh
+    P = {}
+    for nm in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+        P[nm + ".weight"] = (torch.randn(C, C, generator=g) / C ** 0.5).half().float()
+        P[nm + ".bias"] = (0.1 * torch.randn(C, generator=g)).half().float()
+    for nm in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+        P[nm + ".weight"] = (1.0 + 0.2 * torch.randn(dh, generator=g)).half().float()
+    hid = torch.randn(3 * F_, N, C, generator=g).half()
+    hid[2 * F_:] = hid[2 * F_:] * 1.4 + 0.2
+    enc = torch.randn(3 * F_, Nt, C, generator=g).half()
+    for shift, idx in ((False, -1), (True, 12)):
+        w_img, w_txt = sd3_ref.joint_attention(P, heads, hid.float(), enc.float(), idx=idx, shift=shift, eta1=0.0, eta2=0.6, clip_length=F_)
+        g_img, g_txt = nat.sd3_joint_attention({k: v.half().cuda() for k, v in P.items()}, hid.cuda(), enc.cuda(), heads, clip_length=F_, shift=shift,
+                                               idx=idx, eta1=0.0, eta2=0.6)
+        for got, want in ((g_img, w_img), (g_txt, w_txt)):
+            mx, rms = errs(got, want)
+            assert mx < 4e-3 and rms < 1e-3, (shift, mx, rms)
+
+
 def test_linear_gated_epilogue_and_unfused_block_path(nat):
     """Y = residual + gate[b] * gelu_tanh(X W^T + bias) on the small (128-row), split-K and 256 x 320 (ragged N) kernels against torch
     fp32; and a block whose processor does NOT advertise the fused gated residual (a third-party processor) gives the same output

@@ -935,6 +935,367 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// head_dim 64, long sequences (round 3): the joint attention of the SD3 / SD3.5 MM-DiT (4096 image + 333 text tokens per frame at
+// 1024 px, 62 % of that step in attn_body) and the SD-v2.1 layout.  Same software pipeline as attn_pp40_kernel — two score register
+// sets, QK^T of step s+1 on the matrix pipe under the exponentials of step s, PV of step s under the row maxima of step s+1, K/V
+// tiles of 64 keys in a 3-stage LDS ring filled by LDS-DMA in chunk-major planes — with what head_dim 64 changes:
+//   * no padding columns to fold the reference into: Q arrives prescaled (AttnParams::q_prescaled) and the running reference enters
+//     as the ACCUMULATOR of the first QK^T MFMA: cfold[qb] = (lw - M) in all four slots, a persistent fp32 register quad per query
+//     block that changes only when the reference or the source multiplicity does.  The MFMA returns s - M + lw, the exponentials
+//     take it as is; one MFMA family in the loop, so no mixed-family fence (attn_pp40_kernel K16);
+//   * no spare V column for the denominator either: the row sums are taken from the PACKED fp16 probabilities with
+//     v_dot2c_f32_f16 against (1, 1) — one VALU op per two keys, and the denominator is the sum of exactly the values the PV MFMA
+//     multiplies (what the ones column gave the d = 40 kernel);
+//   * 16 data planes per tile and stage (8 K + 8 V), four DMA instructions per wave and tile, no constant planes, no LDS init;
+//   * the EXTRA key segment of the joint attention (AttnParams::kx: the frame's text tokens, own length / stride / buffers,
+//     multiplicity 1) is one more source of the tile sequence.
+// Register budget (2 waves per SIMD: 256): O^T 64 + two score sets 64 + Q 32 + cfold 16 + K / V / P fragments 48 + bookkeeping: 256, no
+// spill.  Measured (12 frames x 24 heads x 4096 queries over 3 x 4096 keys, same box): 3.85 ms = 963 TF against 4.23 ms = 878 TF of
+// attn_body<64, 4, 4>; with ONE wave per SIMD 6.79 ms (546 TF: the second wave hides the tile barrier and the LDS latency); without
+// the sched_group_barrier pins 3.91 ms, with the conversions issued one MFMA later 3.85 ms — the interleave does not matter, because
+// per SIMD the step costs the SUM of its MFMA cycles (32 x 16 = 512) and its VALU / transcendental issue cycles (~450): the two do not
+// overlap across the two waves of a SIMD (tools/probes/coissue_probe.hip) and hardly inside one here.  What is left is less work per
+// key, not a better order.
+template <int TAG = 0>
+__global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
+    constexpr int NW = 4, D = 64, DV16 = 4, QB = 4, NST = 3, NPL = 8;
+    constexpr int KPL = 512, VPL = 576;                      // plane strides in halfs (1024 B / 1152 B: see attn_pp40_kernel STG)
+    constexpr int KAREA = NPL * KPL;
+    constexpr int TILE = NPL * KPL + NPL * VPL;              // 17 KB per stage
+    __shared__ __attribute__((aligned(16))) half_t smem[NST * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int nqb = (p.Nq + 64 * NW - 1) / (64 * NW);
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qblk = lid % nqb;
+    const int h = p.order ? lid / (nqb * p.BF) : (lid / nqb) % p.heads;
+    const int bf = p.order ? (lid / nqb) % p.BF : lid / (nqb * p.heads);
+    const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    const int ntile = (p.Nkv + KT - 1) / KT;
+    const int ntile_x = p.kx ? (p.Nkv_x + KT - 1) / KT : 0;
+    const int nsrc_eff = p.src_cnt ? p.src_cnt[bf] : p.nsrc;
+    const int nseg = nsrc_eff + (p.kx ? 1 : 0);
+    const int T = nsrc_eff * ntile + ntile_x;
+    auto seg_lw = [&](int sidx) { return (sidx < nsrc_eff && p.src_logw) ? p.src_logw[bf * p.nsrc + sidx] : 0.f; };
+    auto seg_nkv = [&](int sidx) { return sidx < nsrc_eff ? p.Nkv : p.Nkv_x; };
+    auto seg_ntile = [&](int sidx) { return sidx < nsrc_eff ? ntile : ntile_x; };
+
+    // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
+    h8 qf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qf[qb][ks] = qrow < p.Nq ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + ks * 32 + g * 8) : zero8;
+    }
+
+    f4 o[DV16][QB], cfold[QB];
+    float mrun[QB], lsum[QB];
+    float lw_cur = seg_lw(0);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        mrun[qb] = 0.f;
+        lsum[qb] = 0.f;
+        cfold[qb] = f4{lw_cur, lw_cur, lw_cur, lw_cur};
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) o[dv][qb] = f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- K/V ring: plane pl (0..7 K chunks, 8..15 V chunks) of a tile is one DMA instruction of wave pl % 4; lane = key row
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const half_t* const zpage = uv_attn_zero_page;
+    const unsigned smem_lds = (unsigned)(size_t)((__attribute__((address_space(3))) half_t*)smem);
+    auto glds16 = [](const half_t* src, unsigned lds_byte) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_byte) : "memory");
+    };
+    // loader state: plain integers only (element offsets from p.k / p.v — the extra segment's buffers are addressed through the
+    // pointer DIFFERENCE kx - k, vx - v).  With pointer-typed state set inside a nested lambda hipcc kept the state in a stack object
+    // and read it back through FLAT loads, which faulted.
+    const long xk_delta = p.kx ? (long)(p.kx - p.k) : 0, xv_delta = p.kx ? (long)(p.vx - p.v) : 0;
+    int ld_s = 0, ld_t = 0;
+    long ld_koff, ld_voff, ld_ld;
+    int ld_nkv, ld_ntile;
+    {
+        const long off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc]) * p.Nkv * p.ldkv + h * D;
+        ld_koff = off; ld_voff = off; ld_ld = p.ldkv; ld_nkv = p.Nkv; ld_ntile = ntile;
+    }
+    auto dma_tile = [&](int stage_half) {
+        const int t0 = ld_t * KT;
+        const bool rok = t0 + lane < ld_nkv;
+        const long roff = (long)(t0 + lane) * ld_ld;
+        const half_t* const ksrc = p.k + ld_koff + roff;
+        const half_t* const vsrc = p.v + ld_voff + roff;
+#pragma unroll
+        for (int j = 0; j < 2 * NPL / NW; ++j) {
+            const int pl = wave_u + NW * j;                      // wave-uniform
+            const bool isv = pl >= NPL;
+            const int c = pl & (NPL - 1);
+            const half_t* src = rok ? (isv ? vsrc : ksrc) + c * 8 : zpage;
+            const int dst = stage_half + (isv ? KAREA + c * VPL : c * KPL);
+            glds16(src, __builtin_amdgcn_readfirstlane(smem_lds + 2u * (unsigned)dst));
+        }
+        if (++ld_t == ld_ntile) {
+            ld_t = 0;
+            ++ld_s;
+            if (ld_s < nsrc_eff) {
+                const long off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc + ld_s]) * p.Nkv * p.ldkv + h * D;
+                ld_koff = off; ld_voff = off;
+            } else if (ld_s < nseg) {
+                const long off = (long)__builtin_amdgcn_readfirstlane(p.x_idx[bf]) * p.Nkv_x * p.ldkv_x + h * D;
+                ld_koff = off + xk_delta; ld_voff = off + xv_delta; ld_ld = p.ldkv_x; ld_nkv = p.Nkv_x; ld_ntile = ntile_x;
+            }
+        }
+    };
+
+    // ---- the pipeline pieces
+    const int kf_off = g * KPL + l15 * 8;
+    const int vf_off = KAREA + ((l15 & 3) >> 1) * VPL + (g * 4 + (l15 >> 2)) * 8 + (l15 & 1) * 4;
+    auto kfrag_read = [&](const half_t* st, int hh, h8 (&kf)[2][2]) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (hh * 32 + kb * 16) * 8 + ks * 4 * KPL]);
+    };
+    auto vfrag_read = [&](const half_t* st, int hh, h8 (&vf)[DV16]) {
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) {
+            const half_t* vp = &st[vf_off + hh * 32 * 8 + dv * 2 * VPL];
+            fh4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp));
+            fh4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(vp + 16 * 8));
+            h8 a;
+            a[0] = (half_t)lo[0]; a[1] = (half_t)lo[1]; a[2] = (half_t)lo[2]; a[3] = (half_t)lo[3];
+            a[4] = (half_t)hi[0]; a[5] = (half_t)hi[1]; a[6] = (half_t)hi[2]; a[7] = (half_t)hi[3];
+            vf[dv] = a;
+        }
+    };
+    auto qk = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {        // S^T - M + lw of one 32-key step: 16 MFMAs, the first eight start from cfold
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], cfold[qb], 0, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], sc[kb][qb], 0, 0, 0);
+    };
+    auto exp_part = [&](const f4 (&sc)[2][QB], h8 (&pb)[QB]) {    // P^T (fp16, B operand of the PV MFMA)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            union { fh2 h[4]; h8 v; } u;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const float e0 = __builtin_amdgcn_exp2f(sc[kb][qb][0]), e1 = __builtin_amdgcn_exp2f(sc[kb][qb][1]);
+                const float e2 = __builtin_amdgcn_exp2f(sc[kb][qb][2]), e3 = __builtin_amdgcn_exp2f(sc[kb][qb][3]);
+                u.h[kb * 2] = __builtin_amdgcn_cvt_pkrtz(e0, e1);
+                u.h[kb * 2 + 1] = __builtin_amdgcn_cvt_pkrtz(e2, e3);
+            }
+            pb[qb] = u.v;
+        }
+    };
+    auto row_sums = [&](const h8 (&pb)[QB]) {                       // denominators from the packed probabilities: v_dot2c_f32_f16 against (1, 1)
+        const fh2 one2 = {(__fp16)1.f, (__fp16)1.f};
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            union { fh2 h[4]; h8 v; } u;
+            u.v = pb[qb];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lsum[qb] = __builtin_amdgcn_fdot2(u.h[i], one2, lsum[qb], false);
+        }
+    };
+    auto pv = [&](const h8 (&vf)[DV16], const h8 (&pb)[QB]) {      // O^T += V^T P^T: 16 MFMAs
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) o[dv][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[dv], pb[qb], o[dv][qb], 0, 0, 0);
+    };
+    auto local_max = [&](const f4 (&sc)[2][QB], float (&mx)[QB]) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float m = max3f(sc[0][qb][0], sc[0][qb][1], sc[0][qb][2]);
+            m = max3f(m, sc[0][qb][3], sc[1][qb][0]);
+            m = max3f(m, sc[1][qb][1], sc[1][qb][2]);
+            mx[qb] = max3f(m, sc[1][qb][3], sc[1][qb][3]);
+        }
+    };
+    auto mask_tail = [&](f4 (&sc)[2][QB], int key0, int nkv) {     // keys >= nkv of a segment's tail tile -> -inf
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key0 + kb * 16 + g * 4 + r >= nkv) sc[kb][qb][r] = -INFINITY;
+    };
+    // reference update for the scores `sc` of the NEXT step (deferred, T13; see attn_pp40_kernel::decide).  M is quantised to 1/64
+    // (softmax is shift invariant); the pending scores move by the same delta, O^T and the row sums are rescaled once per change,
+    // and cfold takes the new reference for every later step.
+    auto decide = [&](f4 (&sc)[2][QB], const float (&mx)[QB], float lw, bool first) {
+        if (!first) {
+            const float mall = fmaxf(max3f(mx[0], mx[1], mx[2]), mx[3]);
+            if (__builtin_amdgcn_ballot_w64(mall > DEFER) == 0) return;
+        }
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            if (__builtin_amdgcn_ballot_w64(first || mx[qb] > DEFER) != 0) {
+                float m = mx[qb];
+                const float o16 = __shfl_xor(m, 16, 64);
+                m = max3f(m, o16, o16);
+                const float o32 = __shfl_xor(m, 32, 64);
+                m = max3f(m, o32, o32);
+                float delta = floorf(m * 64.f + 0.5f) * (1.f / 64.f);              // shifted row max, quantised
+                if (!first) delta = fmaxf(delta, 0.f);
+                if (!(delta > -3.0e38f)) delta = 0.f;                                // a fully masked first step (-inf): keep M
+                mrun[qb] += delta;
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                const float cnew = lw - mrun[qb];
+                cfold[qb] = f4{cnew, cnew, cnew, cnew};
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    sc[kb][qb][0] -= delta; sc[kb][qb][1] -= delta; sc[kb][qb][2] -= delta; sc[kb][qb][3] -= delta;
+                }
+                lsum[qb] *= alpha;
+#pragma unroll
+                for (int dv = 0; dv < DV16; ++dv) {
+                    o[dv][qb][0] *= alpha; o[dv][qb][1] *= alpha; o[dv][qb][2] *= alpha; o[dv][qb][3] *= alpha;
+                }
+            }
+        }
+    };
+    auto set_lw = [&](float lw) {                                  // the next source has another multiplicity
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const float cnew = lw - mrun[qb];
+            cfold[qb] = f4{cnew, cnew, cnew, cnew};
+        }
+    };
+// issue order inside the two overlapped regions (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8, DS read 0x100, TRANS 0x400)
+#define UV_P64_PHASE1()                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                        \
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        \
+    }
+#define UV_P64_PHASE2()                                                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+        if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                        \
+    }
+#define UV_P64_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+
+    // ---- prologue: tiles 0 and 1 into the ring, scores + reference of step (0, 0)
+    dma_tile(0);
+    if (T > 1) dma_tile(TILE);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f4 scA[2][QB], scB[2][QB];
+    h8 kf[2][2], vf[DV16], pb[QB];
+    float mx[QB];
+    int cs_s = 0, cs_t = 0;                                  // (segment, tile in segment) of tile tt
+    int nkv_cur = seg_nkv(0), nkv_nxt = nkv_cur;
+    int nx_s = 0, nx_t = 0;
+    auto advance_nx = [&]() {
+        if (++nx_t == seg_ntile(nx_s)) { nx_t = 0; ++nx_s; }
+    };
+    advance_nx();                                            // -> tile 1
+    float lw_nxt = nx_s < nseg ? seg_lw(nx_s) : lw_cur;
+    nkv_nxt = nx_s < nseg ? seg_nkv(nx_s) : nkv_cur;
+    int t0_cur = 0, t0_nxt = nx_t * KT;
+    half_t* b_cur = smem;
+    half_t* b_nxt = smem + TILE;
+    half_t* b_ld = smem + 2 * TILE;
+    (void)cs_s; (void)cs_t;
+
+    kfrag_read(b_cur, 0, kf);
+    qk(kf, scA);
+    if (t0_cur + KT > nkv_cur) mask_tail(scA, t0_cur, nkv_cur);
+    local_max(scA, mx);
+    decide(scA, mx, lw_cur, true);
+    kfrag_read(b_cur, 1, kf);
+
+    for (int tt = 0; tt < T; ++tt) {
+        const bool has_next = tt + 1 < T;
+        if (tt + 2 < T) dma_tile((int)(b_ld - smem));        // tile tt+2 straight into the stage tile tt-1 left at the last barrier
+        // ---- step (tt, 0): scores of (tt, 1) on the matrix pipe while (tt, 0) is exponentiated
+        vfrag_read(b_cur, 0, vf);
+        qk(kf, scB);
+        exp_part(scA, pb);
+        UV_P64_PIN4(pb);
+        UV_P64_PHASE1();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t0_cur + KT > nkv_cur) mask_tail(scB, t0_cur + 32, nkv_cur);
+        kfrag_read(b_nxt, 0, kf);
+        pv(vf, pb);
+        local_max(scB, mx);
+        row_sums(pb);
+        UV_P64_PIN4(mx);
+        UV_P64_PIN4(lsum);
+        UV_P64_PHASE2();
+        __builtin_amdgcn_sched_barrier(0);
+        decide(scB, mx, lw_cur, false);
+        // ---- step (tt, 1): scores of (tt+1, 0)
+        if (lw_nxt != lw_cur) set_lw(lw_nxt);
+        vfrag_read(b_cur, 1, vf);
+        qk(kf, scA);
+        exp_part(scB, pb);
+        UV_P64_PIN4(pb);
+        UV_P64_PHASE1();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next && t0_nxt + KT > nkv_nxt) mask_tail(scA, t0_nxt, nkv_nxt);
+        kfrag_read(b_nxt, 1, kf);
+        pv(vf, pb);
+        local_max(scA, mx);
+        row_sums(pb);
+        UV_P64_PIN4(mx);
+        UV_P64_PIN4(lsum);
+        UV_P64_PHASE2();
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) decide(scA, mx, lw_nxt, false);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile tt+2 have landed
+        __syncthreads();
+        half_t* tb = b_cur; b_cur = b_nxt; b_nxt = b_ld; b_ld = tb;
+        t0_cur = t0_nxt;
+        nkv_cur = nkv_nxt;
+        lw_cur = lw_nxt;
+        advance_nx();
+        if (nx_s < nseg) {
+            lw_nxt = seg_lw(nx_s);
+            nkv_nxt = seg_nkv(nx_s);
+        }
+        t0_nxt = nx_t * KT;
+    }
+#undef UV_P64_PHASE1
+#undef UV_P64_PHASE2
+#undef UV_P64_PIN4
+
+    // ---- finalize: O^T[d = dv*16 + g*4 + r][q = l15] / l
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        float l = lsum[qb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.f / l;
+        const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
+        if (qrow >= p.Nq) continue;
+        half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
+#pragma unroll
+        for (int dv = 0; dv < DV16; ++dv) {
+            h4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+            *reinterpret_cast<h4*>(op + dv * 16 + g * 4) = ov;
+        }
+    }
+}
+
 // lane l of a 64-lane wave reports what ds_read_b64_tr_b16 returned for a known LDS image (bring-up aid).
 __global__ void tr16_probe_kernel(float* out) {
     __shared__ __attribute__((aligned(16))) half_t sm[64 * 16];
@@ -1140,6 +1501,17 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
             else if (pp == 2 && stg) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else hipLaunchKernelGGL((attn_pp40_kernel<false, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    if constexpr (DPAD == 64 && DV16 == 4) {
+        // head_dim 64 with prescaled q (the SD3 joint attention folds the factor into the q RMSNorm weight): software-pipelined kernel.
+        // UNIVST_ATTN_PP64=0 (A/B aid): the generic body
+        static const int pp64 = getenv("UNIVST_ATTN_PP64") ? atoi(getenv("UNIVST_ATTN_PP64")) : 1;
+        if (pp64 && p.q_prescaled && p.Nq >= 1024) {
+            const int nqb4 = (p.Nq + 255) / 256;
+            hipLaunchKernelGGL((attn_pp64_kernel<0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
             return UV_OK;
         }

@@ -23,7 +23,7 @@ namespace {
 
 // one wave per (row, head): x <- x * rsqrt(mean(x^2) + eps) * w      (d <= 256, multiple of 2)
 __global__ __launch_bounds__(256) void rms_heads_kernel(half_t* __restrict__ x, long ld, long rows, int heads, int d,
-                                                        const half_t* __restrict__ w, float eps) {
+                                                        const half_t* __restrict__ w, float eps, float scl) {
     const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (unit >= rows * heads) return;
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void rms_heads_kernel(half_t* __restrict__ x, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int e = lane + 64 * i;
-        if (e < d) p[e] = (half_t)(v[i] * r_ * (float)w[e]);
+        if (e < d) p[e] = (half_t)(v[i] * r_ * (float)w[e] * scl);
     }
 }
 
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void rms_heads_kernel(half_t* __restrict__ x, 
 // c1 < 0: one block).  HBM-bound: 2 x 2 x rows x heads x d bytes per call.
 template <int LPH>
 __global__ __launch_bounds__(256) void rms_heads_vec_kernel(half_t* __restrict__ x, long ld, long rows, int heads, long c0, long c1,
-                                                            const half_t* __restrict__ w0, const half_t* __restrict__ w1, float eps) {
+                                                            const half_t* __restrict__ w0, const half_t* __restrict__ w1, float eps, float scl0) {
     constexpr int D = LPH * 8;
     const long per_row = (long)heads * LPH;                       // 16-byte pieces per row and column block
     const long nblk = c1 >= 0 ? 2 : 1;
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void rms_heads_vec_kernel(half_t* __restrict__
     for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
 #pragma unroll
     for (int o = 1; o < LPH; o <<= 1) ss += __shfl_xor(ss, o, 64);
-    const float r_ = rsqrtf(ss / D + eps);
+    const float r_ = rsqrtf(ss / D + eps) * (blk ? 1.f : scl0);      // scl0: the attention's scale * log2(e) rides on the q block (one rounding)
     const h8 wv = *reinterpret_cast<const h8*>((blk ? w1 : w0) + e0);
     h8 o;
 #pragma unroll
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void rms_heads_vec_kernel(half_t* __restrict__
 
 // launcher: q and k of a fused buffer in one pass when the head width allows (w1 / c1 optional)
 static int launch_rms_pair(half_t* x, long ld, long rows, int heads, int d, long c0, const half_t* w0, long c1, const half_t* w1, float eps,
-                           hipStream_t s) {
+                           hipStream_t s, float scl0 = 1.f) {
     const bool two = w1 != nullptr;
     const bool vec = (d == 32 || d == 64 || d == 128) && ld % 8 == 0 && c0 % 8 == 0 && (!two || c1 % 8 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w0) | reinterpret_cast<uintptr_t>(w1)) & 15) == 0;
@@ -87,12 +87,12 @@ static int launch_rms_pair(half_t* x, long ld, long rows, int heads, int d, long
         const long n = rows * heads * (d / 8) * (two ? 2 : 1);
         const dim3 grid((unsigned)((n + 255) / 256));
         const long cc1 = two ? c1 : -1;
-        if (d == 32) hipLaunchKernelGGL(rms_heads_vec_kernel<4>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps);
-        else if (d == 64) hipLaunchKernelGGL(rms_heads_vec_kernel<8>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps);
-        else hipLaunchKernelGGL(rms_heads_vec_kernel<16>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps);
+        if (d == 32) hipLaunchKernelGGL(rms_heads_vec_kernel<4>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps, scl0);
+        else if (d == 64) hipLaunchKernelGGL(rms_heads_vec_kernel<8>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps, scl0);
+        else hipLaunchKernelGGL(rms_heads_vec_kernel<16>, grid, dim3(256), 0, s, x, ld, rows, heads, c0, cc1, w0, w1, eps, scl0);
     } else {
-        hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, s, x + c0, ld, rows, heads, d, w0, eps);
-        if (two) hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, s, x + c1, ld, rows, heads, d, w1, eps);
+        hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, s, x + c0, ld, rows, heads, d, w0, eps, scl0);
+        if (two) hipLaunchKernelGGL(rms_heads_kernel, dim3((unsigned)((rows * heads + 3) / 4)), dim3(256), 0, s, x + c1, ld, rows, heads, d, w1, eps, 1.f);
     }
     UV_LAUNCH_CHECK();
     return UV_OK;
@@ -473,7 +473,11 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         RUN(linear(x, Cin, rows_i, Cin, H(w->to_q), H(w->to_q_bias), C, qkv_i, 3 * C, s));
         RUN(linear(x, Cin, rows_i, Cin, H(w->to_k), H(w->to_k_bias), C, qkv_i + C, 3 * C, s));
         RUN(linear(x, Cin, rows_i, Cin, H(w->to_v), H(w->to_v_bias), C, qkv_i + 2 * C, 3 * C, s));
-        if (w->norm_q && w->norm_k) RUN(launch_rms_pair(qkv_i, 3 * C, rows_i, heads, head_dim, 0, H(w->norm_q), C, H(w->norm_k), rms_eps, s));
+        // with q / k RMSNorm (SD3.5) the attention's scale * log2(e) is applied to q inside the norm (one fp16 rounding, as the norm's
+        // own output has): the attention then runs with AttnParams::q_prescaled, which the pipelined head_dim-64 kernel needs
+        const float qscale = 1.4426950408889634f / sqrtf((float)head_dim);
+        const bool presc = w->norm_q && w->norm_k && (!enc || (w->norm_added_q && w->norm_added_k));
+        if (w->norm_q && w->norm_k) RUN(launch_rms_pair(qkv_i, 3 * C, rows_i, heads, head_dim, 0, H(w->norm_q), C, H(w->norm_k), rms_eps, s, presc ? qscale : 1.f));
         else if (w->norm_q) RUN(univst_rmsnorm_heads(qkv_i, 3 * C, rows_i, heads, head_dim, w->norm_q, rms_eps, s));
         else if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
         if (shift && (float)idx >= eta1 * 50.f && (float)idx <= eta2 * 50.f) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0)
@@ -486,7 +490,7 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             RUN(linear(e, Cin, rows_t, Cin, H(w->add_k), H(w->add_k_bias), C, qkv_t + C, 3 * C, s));
             RUN(linear(e, Cin, rows_t, Cin, H(w->add_v), H(w->add_v_bias), C, qkv_t + 2 * C, 3 * C, s));
             if (w->norm_added_q && w->norm_added_k)
-                RUN(launch_rms_pair(qkv_t, 3 * C, rows_t, heads, head_dim, 0, H(w->norm_added_q), C, H(w->norm_added_k), rms_eps, s));
+                RUN(launch_rms_pair(qkv_t, 3 * C, rows_t, heads, head_dim, 0, H(w->norm_added_q), C, H(w->norm_added_k), rms_eps, s, presc ? qscale : 1.f));
             else if (w->norm_added_q) RUN(univst_rmsnorm_heads(qkv_t, 3 * C, rows_t, heads, head_dim, w->norm_added_q, rms_eps, s));
             else if (w->norm_added_k) RUN(univst_rmsnorm_heads(qkv_t + C, 3 * C, rows_t, heads, head_dim, w->norm_added_k, rms_eps, s));
         }
@@ -529,7 +533,8 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         AttnParams a;
         a.k = qkv_i + C; a.v = qkv_i + 2 * C; a.ldkv = 3 * C;
         a.src_idx = tab; a.nsrc = 3; a.src_cnt = tab + 4 * B; a.src_logw = (const float*)(tab + 5 * B); a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
-        a.scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+        a.scale_log2e = qscale;
+        a.q_prescaled = presc ? 1 : 0;
         if (enc) { a.kx = qkv_t + C; a.vx = qkv_t + 2 * C; a.ldkv_x = 3 * C; a.Nkv_x = Nt; a.x_idx = tab + 3 * B; }
         a.q = qkv_i; a.ldq = 3 * C; a.Nq = N; a.o = o_i; a.ldo = C;
         RUN(uv_launch_attention(a, s));                                  // image queries over [first | prev | cur] ++ text keys
