@@ -59,6 +59,7 @@ def parse():
                                                                     "line); no GPU work, runs on a CPU box with --backend gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-shard-check", action="store_true", help="multi-rank runs: skip the sharded-vs-unsharded forward check before timing")
     ap.add_argument("--no-skip-dead-branches-leg", action="store_true",
                     help="do not also time the variant that drops branches 0/1 after the PnP window (identical output; reported "
                          "separately in config, never as `value`)")
@@ -433,6 +434,7 @@ def main():
         pnp_utils.register_spatial_attention_pnp(pipe)
     masked = a.workload == "transfer"
     content, style, text3, mask = synth.synth_transfer_inputs(F=F_total, h=h, w=h, D=1024 if a.model == "sd21" else 768, device=dev, with_mask=masked, mask_hw=8 * h)
+    content_full, style_full = content[50], style[50]          # (kept for the sharded self-check below)
     content = [shard.slice_frames(t) for t in content]
     style = [shard.slice_frames(t) for t in style]
     mask_m = None
@@ -440,6 +442,51 @@ def main():
         mask_m = _native.mask_resize(mask.reshape(-1, 8 * h, 8 * h).contiguous(), h, h)
         mask_m = mask_m.reshape(-1, h, h)[shard.f0:shard.f0 + shard.local].contiguous()
     shard.attach(unet, max_tokens=h * h)
+    shard_check = None
+    if world > 1 and not a.no_shard_check:
+        # First contact with real multi-GPU hardware happens in the driver's run: before anything is timed, every rank compares ONE
+        # frame-sharded forward (inside the PnP window: K/V exchange, GroupNorm all-reduces) with the unsharded forward of a second
+        # UNet instance on the whole clip.  A communicator that fails the check — wrong numbers, a refused mapping, a bounded wait
+        # that gave up — is replaced: library IPC -> torch.distributed callbacks; if that fails too the run stops with the evidence.
+        from univst_amd.backbones.video_diffusion_sd.pnp_utils import register_time
+        ref_unet = synth.build_unet(config=synth.SD21_UNET_CONFIG if a.model == "sd21" else None, device=dev, seed=33)
+        ref_pipe = Pipe(ref_unet, pipe.scheduler)
+        if not a.workload.startswith("inversion"):
+            pnp_utils.register_spatial_attention_pnp(ref_pipe)
+        register_time(ref_pipe, 10)
+        xf = torch.cat([content_full, style_full, 0.5 * (content_full + style_full)])
+        want = ref_unet(xf, 781, encoder_hidden_states=text3).sample[:, :, shard.f0:shard.f0 + shard.local].float()
+        del ref_unet, ref_pipe
+
+        def check_once():
+            try:
+                register_time(pipe, 10)
+                got = unet(torch.cat([shard.slice_frames(t) for t in (content_full, style_full, 0.5 * (content_full + style_full))]), 781,
+                           encoder_hidden_states=text3).sample.float()
+                torch.cuda.synchronize()
+                err = float((got - want).abs().max() / want.abs().max())
+            except Exception as e:      # noqa: BLE001  (a failed collective surfaces as RuntimeError out of the native call)
+                err = float("inf")
+                print(f"[bench] rank {rank}: sharded self-check raised {type(e).__name__}: {e}", flush=True)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            return max(errs)
+
+        err = check_once()
+        kind = type(shard.comm).__name__
+        shard_check = {"comm": kind, "max_rel_err_vs_unsharded": err}
+        if not err < 2e-2:
+            if rank == 0:
+                print(f"[bench] frame-sharded forward through {kind} differs from the unsharded one (max rel err {err}); "
+                      "switching to the torch.distributed callbacks", flush=True)
+            os.environ["UNIVST_COMM"] = "dist"
+            shard = FrameShard(rank, world, F_total)
+            shard.attach(unet, max_tokens=h * h)
+            err2 = check_once()
+            shard_check = {"comm": type(shard.comm).__name__, "max_rel_err_vs_unsharded": err2, "rejected": {"comm": kind, "max_rel_err": err}}
+            if not err2 < 2e-2:
+                raise RuntimeError(f"frame-sharded forward is wrong through both communicators ({kind}: {err}, {type(shard.comm).__name__}: {err2})")
+        del want
     sharded = world > 1 or emu is not None
     inv = a.workload.startswith("inversion")
     pair = a.workload == "inversion_pair"
@@ -496,7 +543,7 @@ def main():
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "schedule_steps": "all 50" if a.steps == 50 else (f"{a.steps} of 50, evenly spread" if a.steps < 50 else f"{a.steps} (wrapping modulo 50)"),
                    "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
-                   "comm": None if world == 1 else type(shard.comm).__name__,
+                   "comm": None if world == 1 else type(shard.comm).__name__, "shard_check": shard_check,
                    "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else
                                "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16")},
     }
