@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=16)
-    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--latent", type=int, default=None, help="latent side (default: 64 = 512 px; 128 = 1024 px for --workload sd3_transfer)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl == RCCL; gloo stages through the host, bring-up only)")
     ap.add_argument("--comm", default=None, choices=["ipc", "dist"],
                     help="frame-shard communicator for --gpus > 1: ipc = the library's own (HIP IPC peer writes + device flags, no host "
@@ -257,7 +257,7 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
     from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
     from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
     from univst_amd.parallel import Sd3FrameShard
-    F_all, hl = a.frames, a.latent * 2 if a.latent == 64 else a.latent       # default --latent 64 is the SD-v1.5 size: 128 here (1024 px)
+    F_all, hl = a.frames, a.latent
     shard = Sd3FrameShard(rank, world, F_all)
     F_ = shard.local
     torch.manual_seed(33)
@@ -376,6 +376,8 @@ def launch_selftest(a, rank, world):
 
 def main():
     a = parse()
+    if a.latent is None:
+        a.latent = 128 if a.workload == "sd3_transfer" else 64
     if a.comm:
         os.environ["UNIVST_COMM"] = a.comm
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.emulate_rank:
