@@ -113,3 +113,21 @@ def test_frame_shard_slicing():
     assert torch.equal(torch.cat(parts, 2), t)
     with pytest.raises(ValueError):
         FrameShard(0, 3, 16)
+
+
+def test_sd3_frame_shard_slicing():
+    """SD3 path: frames are the batch axis and the three branches are concatenated along it; a rank holds the same frame range of
+    every branch.  (The K/V exchange itself lives in the native library and is tested by two processes on a GPU.)"""
+    from univst_amd.parallel import Sd3FrameShard
+    F_, W = 16, 4
+    t = torch.arange(3 * F_ * 2).view(3 * F_, 2)
+    parts = [Sd3FrameShard(r, W, F_).slice_branches(t) for r in range(W)]
+    assert all(p.shape == (3 * F_ // W, 2) for p in parts)
+    # re-assemble branch by branch: [branch][rank][local frame] -> the original order
+    back = torch.cat([torch.cat([p.chunk(3)[b] for p in parts]) for b in range(3)])
+    assert torch.equal(back, t)
+    sh = Sd3FrameShard(2, W, F_)
+    assert (sh.f0, sh.local) == (8, 4) and torch.equal(sh.slice_frames(t[:F_]), t[8:12])
+    assert Sd3FrameShard(0, 1, F_).gather_frames(t) is t
+    with pytest.raises(ValueError):
+        Sd3FrameShard(0, 3, 16)
