@@ -28,6 +28,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats_sd3 -- pyth
 cp $(ls $O/raw/stats_sd3/*/*kernel_stats.csv | head -1) $O/round${ROUND}_kernel_stats_sd3_transfer.csv
 # two ranks on this ONE GPU through the library's IPC communicator: evidence that the multi-rank path executes end to end (not a scaling number)
 python bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_two_ranks_one_gpu.json 2>> $O/raw/bench.err
+python bench.py --gpus 8 --backend gloo --steps 4 --warmup 1 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_eight_ranks_one_gpu.json 2>> $O/raw/bench.err
 tools/probes/coissue_probe > $O/round${ROUND}_coissue_probe.txt 2>&1
 tools/probes/ipc_probe 1 > $O/round${ROUND}_ipc_probe.txt 2>&1
 ROUND=$ROUND python tools/summarize_profiles.py $O
