@@ -510,7 +510,10 @@ def _sd3_shard_rank(rank, world, port, q):
         q.put((rank, None, traceback.format_exc()))
 
 
-def test_sd3_frame_shard_two_processes_ipc(nat):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sd3_frame_shard_two_processes_ipc(nat, world):
+    """world 2: eight frames per rank; world 8: two frames per rank (rank 1's previous frame is also the clip's second one, every rank
+    but 0 takes both halo blocks from the communicator, rank 0 multicasts to seven peers)."""
     import socket
     import torch.multiprocessing as mp
     from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
@@ -528,7 +531,6 @@ def test_sd3_frame_shard_two_processes_ipc(nat):
     sk.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    world = 2
     procs = [mpc.Process(target=_sd3_shard_rank, args=(r, world, port, q)) for r in range(world)]
     for pr in procs:
         pr.start()
