@@ -447,48 +447,12 @@ def main():
     shard_check = None
     if world > 1 and not a.no_shard_check:
         # First contact with real multi-GPU hardware happens in the driver's run: before anything is timed, every rank compares ONE
-        # frame-sharded forward (inside the PnP window: K/V exchange, GroupNorm all-reduces) with the unsharded forward of a second
-        # UNet instance on the whole clip.  A communicator that fails the check — wrong numbers, a refused mapping, a bounded wait
+        # frame-sharded forward (inside the PnP window: K/V exchange, GroupNorm all-reduces) with the unsharded forward of the same
+        # UNet (communicator detached) on the whole clip.  A communicator that fails the check — wrong numbers, a refused mapping, a bounded wait
         # that gave up — is replaced: library IPC -> torch.distributed callbacks; if that fails too the run stops with the evidence.
-        from univst_amd.backbones.video_diffusion_sd.pnp_utils import register_time
-        ref_unet = synth.build_unet(config=synth.SD21_UNET_CONFIG if a.model == "sd21" else None, device=dev, seed=33)
-        ref_pipe = Pipe(ref_unet, pipe.scheduler)
-        if not a.workload.startswith("inversion"):
-            pnp_utils.register_spatial_attention_pnp(ref_pipe)
-        register_time(ref_pipe, 10)
-        xf = torch.cat([content_full, style_full, 0.5 * (content_full + style_full)])
-        want = ref_unet(xf, 781, encoder_hidden_states=text3).sample[:, :, shard.f0:shard.f0 + shard.local].float()
-        del ref_unet, ref_pipe
-
-        def check_once():
-            try:
-                register_time(pipe, 10)
-                got = unet(torch.cat([shard.slice_frames(t) for t in (content_full, style_full, 0.5 * (content_full + style_full))]), 781,
-                           encoder_hidden_states=text3).sample.float()
-                torch.cuda.synchronize()
-                err = float((got - want).abs().max() / want.abs().max())
-            except Exception as e:      # noqa: BLE001  (a failed collective surfaces as RuntimeError out of the native call)
-                err = float("inf")
-                print(f"[bench] rank {rank}: sharded self-check raised {type(e).__name__}: {e}", flush=True)
-            errs = [None] * world
-            dist.all_gather_object(errs, err)
-            return max(errs)
-
-        err = check_once()
-        kind = type(shard.comm).__name__
-        shard_check = {"comm": kind, "max_rel_err_vs_unsharded": err}
-        if not err < 2e-2:
-            if rank == 0:
-                print(f"[bench] frame-sharded forward through {kind} differs from the unsharded one (max rel err {err}); "
-                      "switching to the torch.distributed callbacks", flush=True)
-            os.environ["UNIVST_COMM"] = "dist"
-            shard = FrameShard(rank, world, F_total)
-            shard.attach(unet, max_tokens=h * h)
-            err2 = check_once()
-            shard_check = {"comm": type(shard.comm).__name__, "max_rel_err_vs_unsharded": err2, "rejected": {"comm": kind, "max_rel_err": err}}
-            if not err2 < 2e-2:
-                raise RuntimeError(f"frame-sharded forward is wrong through both communicators ({kind}: {err}, {type(shard.comm).__name__}: {err2})")
-        del want
+        # (the check lives in the product: parallel.FrameShard.self_check is what video_style_transfer runs under torchrun too;
+        # its reference is the SAME UNet with the communicator detached, on the whole clip)
+        shard_check = shard.self_check(pipe, content_full, style_full, text3)
     sharded = world > 1 or emu is not None
     inv = a.workload.startswith("inversion")
     pair = a.workload == "inversion_pair"

@@ -112,7 +112,10 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
 
 /* tuning switches of a handle (not part of the reference's surface; tests use them for A/B runs).
  *   "ln_fold" (default 1, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
- *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU). */
+ *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU).
+ *   "chain_bands" (default 0 = auto, env UNIVST_CHAIN_BANDS): the row-local chain behind a transformer block's self-attention
+ *             (to_out -> attn2 -> to_out -> GEGLU feed-forward, attention.py:316-329) runs band by band over whole frames so that a band's
+ *             intermediates stay in the 256 MB Infinity Cache: auto = bands of >= 65 536 rows, 1 = off, n = n bands.  Bit-identical. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
@@ -174,8 +177,10 @@ int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, i
                      int heads, int head_dim, int q_prescaled, void* stream);
 /* ---- first vertical slice of the SD3 / SD3.5 rectified-flow path (the reference-owned pieces only) ----
  * The joint-attention processors of backbones/video_diffusion_sd3/pnp_utils.py: CrossFrameProcessor (:17-131; shift = 0) and
- * AttentionShiftProcessor (:143-271; shift = 1, window eta1*50 <= idx <= eta2*50, alpha 0.8 / gamma 2.0 / beta 0.9 -> 0.1, under the
- * documented fixed reading thresh2 == eta2 — the reference reads an attribute it never sets).  hidden [B, N, Cin] image tokens of
+ * AttentionShiftProcessor (:143-271; shift = 1 applies the AdaIN shift with alpha 0.8 / gamma 2.0 and the given beta.  The window test
+ * eta1*50 <= idx <= eta2*50 and beta = 0.9 -> 0.1 over the window are evaluated by the CALLER in double, as the reference's Python does
+ * (pnp_utils.py:183-186) — in fp32, eta1 = 0.3 makes 0.3f*50 = 15.000001 and step 15 falls out of the window — under the documented
+ * fixed reading thresh2 == eta2: the reference reads an attribute it never sets).  hidden [B, N, Cin] image tokens of
  * B = (branches x clip_length) frames, enc [B, Nt, Cin] text tokens or NULL; keys of frame f = image tokens of ['first', f-1, f]
  * of its clip (read by pointer) ++ its text tokens (one extra key segment); out_img [B, N, Cin], out_txt [B, Nt, Cin].
  * clip_length == 0: no cross-frame gather — keys of frame f are its own image tokens ++ its text tokens (diffusers' stock
@@ -197,7 +202,7 @@ typedef struct {
     int64_t ld_gate_img, ld_gate_txt;
 } univst_sd3_gated_residual;
 int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin,
-                               int heads, int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps,
+                               int heads, int head_dim, int clip_length, int shift, float beta, float rms_eps,
                                void* out_img, void* out_txt, const univst_sd3_gated_residual* gated_residual /* may be NULL */,
                                univst_comm* comm /* may be NULL */, void* stream);
 /* comm (frame shard, world > 1): the batch holds frames [rank*clip_length, (rank+1)*clip_length) of every branch; K | V of the clip's
@@ -272,6 +277,11 @@ int univst_maskprop_finalize(const float* segs, uint8_t* mask_out, int ncls, int
  * by fwd, occluded pixels take `key`.  key/now uint8 [H,W,3], fwd/bwd f32 [H,W,2]. */
 int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int H,
                            int W, float threshold, void* stream);
+/* The whole window mean of ONE key frame in one launch (stable_diffusion.py:731-747, the inner loop over bias = -r .. r): frames
+ * uint8 [F,H,W,3] is the Gauss-Seidel working copy, frame `key` is replaced in place by trunc(mean of {itself, get_warp(key, key+b)});
+ * flows fp32 [nn][2][H][W][2] = (forward key -> key+b, backward key+b -> key) of the nn in-clip neighbours in increasing b.
+ * Same arithmetic as univst_warp_accumulate + univst_accumulate_u8 + univst_window_store (bit-identical), 1 launch instead of 2r + 2. */
+int univst_warp_window_key(uint8_t* frames, const float* flows, int F, int H, int W, int key, int r, float threshold, void* stream);
 /* latent-space sliding window (no reference code exists for it — definition in csrc/warp.hip and DESIGN.md):
  * x0 [C,F,h,w] fp16 in place, lflow [F, 2r+1, h, w, 2] fp32 = flow from frame k to frame k+b in latent-pixel units. */
 int univst_latent_window_smooth(void* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, void* stream);

@@ -71,7 +71,7 @@ SIGNATURES = {
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _F, _P, _P,
+    "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P,
                                         C.POINTER(Sd3GatedResidual), _P, _P]),
     "univst_sd3_adain_shift": (_I, [_P, _L, _I, _I, _I, _I, _F, _F, _F, _P, _P]),
     "univst_rmsnorm_heads": (_I, [_P, _L, _L, _I, _I, _P, _F, _P]),
@@ -94,6 +94,7 @@ SIGNATURES = {
     "univst_maskprop_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "univst_maskprop_finalize": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "univst_warp_accumulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "univst_warp_window_key": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "univst_latent_window_smooth": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "univst_accumulate_u8": (_I, [_P, _P, _L, _P]),
     "univst_window_store": (_I, [_P, _F, _P, _L, _P]),
@@ -295,8 +296,11 @@ def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False,
         gt = fuse.get("gate_txt")
         gr = Sd3GatedResidual(ptr(_f16(fuse["res_img"])), ptr(fuse["gate_img"]), ptr(fuse.get("res_txt")), ptr(gt), _mod_ld(fuse["gate_img"]),
                               0 if gt is None else _mod_ld(gt))
-    check(load().univst_sd3_joint_attention(C.byref(w), ptr(hidden), ptr(enc), B, N, Nt, Cin, heads, inner // heads, clip_length, int(bool(shift)),
-                                            int(idx), eta1, eta2, rms_eps, ptr(out_i), ptr(out_t), C.byref(gr) if gr is not None else None,
+    # pnp_utils.py:183-186 in Python double, like the reference: in fp32 eta1 = 0.3 gives 0.3f * 50 = 15.000001 and idx 15 drops out
+    active = bool(shift) and idx >= eta1 * 50 and idx <= eta2 * 50
+    beta = ((0.9 - 0.1) / (eta1 * 50 - eta2 * 50) * (idx - eta2 * 50) + 0.1) if active else 0.0
+    check(load().univst_sd3_joint_attention(C.byref(w), ptr(hidden), ptr(enc), B, N, Nt, Cin, heads, inner // heads, clip_length, int(active),
+                                            float(beta), rms_eps, ptr(out_i), ptr(out_t), C.byref(gr) if gr is not None else None,
                                             comm, stream_ptr()), "sd3_joint_attention")
     return (out_i, out_t) if enc is not None else out_i
 

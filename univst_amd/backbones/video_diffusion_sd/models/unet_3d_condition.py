@@ -234,6 +234,21 @@ _DOWN = ("CrossAttnDownBlockPseudo3D", "CrossAttnDownBlockPseudo3D", "CrossAttnD
 _UP = ("UpBlockPseudo3D", "CrossAttnUpBlockPseudo3D", "CrossAttnUpBlockPseudo3D", "CrossAttnUpBlockPseudo3D")
 
 
+_REGISTRATION_EPOCH = [0]
+
+
+def _bump_registration_epoch(*_args):
+    _REGISTRATION_EPOCH[0] += 1
+
+
+try:        # (torch >= 2.0)
+    from torch.nn.modules.module import register_module_parameter_registration_hook, register_module_buffer_registration_hook
+    register_module_parameter_registration_hook(_bump_registration_epoch)
+    register_module_buffer_registration_hook(_bump_registration_epoch)
+except ImportError:       # pragma: no cover
+    pass
+
+
 class UNetPseudo3DConditionModel(nn.Module):
     def __init__(self, sample_size: Optional[int] = None, in_channels: int = 4, out_channels: int = 4,
                  center_input_sample: bool = False, flip_sin_to_cos: bool = True, freq_shift: int = 0,
@@ -392,7 +407,11 @@ class UNetPseudo3DConditionModel(nn.Module):
         ``UNIVST_STRICT_WEIGHTS=1`` runs that check before every forward."""
         ts = self.__dict__.get("_native_tensors")
         n = self.__dict__["_native_fp_calls"] = self.__dict__.get("_native_fp_calls", 0) + 1
-        if ts is None or self._native_dirty or n % 64 == 0:      # (a Parameter object swapped on a submodule shows up at the next refresh)
+        # a Parameter / buffer object (re)registered on ANY module of the process (``m.weight = nn.Parameter(...)``, parametrize / LoRA
+        # wrappers) bumps _REGISTRATION_EPOCH through torch's global registration hooks: the cached tensor list is then rebuilt on
+        # the very next forward, not at the periodic refresh
+        if ts is None or self._native_dirty or n % 64 == 0 or self.__dict__.get("_native_epoch") != _REGISTRATION_EPOCH[0]:
+            self.__dict__["_native_epoch"] = _REGISTRATION_EPOCH[0]
             ts = self._native_tensors = list(self.state_dict(keep_vars=True).values())
         acc = 0
         for t in ts:

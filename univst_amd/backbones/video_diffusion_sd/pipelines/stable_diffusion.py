@@ -9,6 +9,12 @@ sliding-window smoothing that is dead code in the reference (:715), ``smoother='
 latent-space variant the reference's README describes but does not implement, ``content_inv_latents`` /
 ``style_inv_latents`` / ``masks`` accept in-memory tensors instead of paths, ``output_type='latent'`` skips
 the VAE, ``skip_dead_branches`` (see engine.transfer_loop).
+
+Multi-GPU (BASELINE config 4): when the process is one of N started by ``torchrun --nproc-per-node N`` (a
+``torch.distributed`` process group exists), ``video_style_transfer`` shards the clip's frames over the ranks by itself —
+``shard=None`` (default) builds ``parallel.FrameShard`` for the group, checks one sharded forward against the unsharded one
+and falls back IPC -> RCCL callbacks (``parallel.FrameShard.self_check``); ``shard=False`` keeps every rank on the whole clip;
+an explicit ``FrameShard`` is used as is.  Every rank gets the full latents back; only rank 0 decodes (``.images`` is None elsewhere).
 """
 import inspect
 from typing import Callable, List, Optional, Union
@@ -210,7 +216,7 @@ class SpatioTemporalStableDiffusionPipeline:
                              generator=None, latents=None, output_type="tensor", return_dict=True, callback=None,
                              callback_steps=1, content_inv_path=None, style_inv_path=None, mask_path=None,
                              content_inv_latents=None, style_inv_latents=None, masks=None, smoother=None, flow_fn=None,
-                             latent_flows=None, skip_dead_branches=False, **kwargs):
+                             latent_flows=None, skip_dead_branches=False, shard=None, **kwargs):
         if eta != 0.0:
             raise NotImplementedError("eta != 0")
         device = self._execution_device
@@ -255,6 +261,16 @@ class SpatioTemporalStableDiffusionPipeline:
                 frames = sliding_window_smooth(frames, flow_fn, m01)
                 return engine.return_to_timestep(self.scheduler, t, lat, self.get_latent_image(frames))
         cb = (lambda i, t, l: callback(i, t, l) if i % callback_steps == 0 else None) if callback is not None else None
+        if shard is None:            # one process per GPU under torchrun: shard the frames (checked once per pipeline and geometry)
+            from ....parallel import auto_frame_shard, dist_rank_world
+            if dist_rank_world()[1] > 1:
+                shard = auto_frame_shard(self, F_, latents.shape[-2:], check_inputs=(content_inv_latents[n].to(device), style_inv_latents[n].to(device), text3))
+        if shard is False or (shard is not None and shard.world == 1):
+            shard = None
+        if shard is not None and skip_dead_branches:
+            raise NotImplementedError("skip_dead_branches with a frame shard (the single-branch call has its own K/V exchange schedule)")
         latents = engine.transfer_loop(self, latents.to(device), text3, content_inv_latents, style_inv_latents, masks, n,
-                                       smoother=sm, callback=cb, skip_dead_branches=skip_dead_branches)
+                                       smoother=sm, callback=cb, skip_dead_branches=skip_dead_branches, shard=shard)
+        if shard is not None and shard.rank != 0 and output_type != "latent":      # rank 0 decodes and writes; the others are done
+            return StableDiffusionPipelineOutput(images=None) if return_dict else (None, None)
         return self._finish(latents, output_type, return_dict)

@@ -193,9 +193,16 @@ class CustomStableDiffusion3Pipeline:
                              negative_pooled_prompt_embeds=None, output_type="pil", return_dict=True, callback_on_step_end=None,
                              callback_on_step_end_tensor_inputs=("latents",), max_sequence_length=256, mu=None,
                              content_inv_path=None, style_inv_path=None, mask_path=None, eta_base=0.95, eta_trend="constant", start_step=10,
-                             end_step=20, img_latents=None, content_inv_latents=None, style_inv_latents=None):
+                             end_step=20, img_latents=None, content_inv_latents=None, style_inv_latents=None, shard=None, masks=None):
         """``content_inv_latents`` / ``style_inv_latents`` (addition): the per-step inversion latents in memory (lists indexed by the
-        step label k of ``ddim_latents_{k}.pt``) instead of ``*_inv_path`` — the in-process hand-off of SURVEY §8f-1."""
+        step label k of ``ddim_latents_{k}.pt``) instead of ``*_inv_path`` — the in-process hand-off of SURVEY §8f-1; ``masks`` the
+        ``load_mask`` tensor in memory instead of ``mask_path``.
+
+        ``shard`` (addition, BASELINE config 5 on N GPUs): under ``torchrun --nproc-per-node N`` (a process group exists) the clip's
+        frames are split over the ranks — ``None`` builds ``parallel.Sd3FrameShard`` for the group (K | V of the first and the previous
+        frame travel through the library's IPC communicator inside every joint attention), ``False`` keeps the whole clip on every rank,
+        an explicit ``Sd3FrameShard`` is used as is.  All arguments are the full clip on every rank; every rank gets the full latents
+        back and rank 0 decodes (``.images`` is None elsewhere unless ``output_type='latent'``)."""
         if latents is None or img_latents is None:
             raise ValueError("video_style_transfer needs `latents` (the shifted content noise) and `img_latents`")
         if callback_on_step_end is not None:
@@ -204,22 +211,38 @@ class CustomStableDiffusion3Pipeline:
         pe, _, pp, _ = self.encode_prompt(prompt=prompt, prompt_2=prompt_2, prompt_3=prompt_3, do_classifier_free_guidance=False,
                                           prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
                                           num_images_per_prompt=num_images_per_prompt, max_sequence_length=max_sequence_length)
+        F_all = latents.shape[0]
+        if shard is None:
+            from ....parallel import Sd3FrameShard, dist_rank_world
+            rank, world = dist_rank_world()
+            if world > 1:
+                key = (rank, world, F_all, tuple(latents.shape[-2:]))
+                cache = self.__dict__.setdefault("_univst_shards", {})
+                if key not in cache:
+                    ps = self.transformer.config.patch_size
+                    cache[key] = Sd3FrameShard(rank, world, F_all).attach(self.transformer, tokens=(latents.shape[-2] // ps) * (latents.shape[-1] // ps))
+                shard = cache[key]
+        if shard is False or (shard is not None and shard.world == 1):
+            shard = None
+        cut = shard.slice_frames if shard is not None else (lambda t: t)
+        latents, target = cut(_f16(latents)), cut(_f16(img_latents))
         F_ = latents.shape[0]
         pe_all = _f16(pe).repeat(3 * F_, 1, 1)                       # custom_pipeline.py:226-227
         pp_all = _f16(pp).repeat(3 * F_, 1)
-        latents, target = _f16(latents), _f16(img_latents)
         ts, tl, ds = self._schedule(num_inference_steps, sigmas)
         n = len(tl)
         eta_values = self.generate_eta_values(tl, start_step, end_step, eta_base, eta_trend)
         T = self.scheduler.config.num_train_timesteps
 
         def inv(store, path, k):
-            return _f16(store[k] if store is not None else load_ddim_latents_at_t(k, path))
+            return cut(_f16(store[k] if store is not None else load_ddim_latents_at_t(k, path)))
 
         mask = None
-        if mask_path:                                                # load_mask + bilinear resize once (the reference redoes both per step)
-            m = load_mask(mask_path, n_frames=F_)
+        if mask_path or masks is not None:                           # load_mask + bilinear resize once (the reference redoes both per step)
+            m = masks if masks is not None else load_mask(mask_path, n_frames=F_all)
             mask = _native.mask_resize(m[0].to("cuda").contiguous(), latents.shape[-2], latents.shape[-1])
+            if shard is not None:
+                mask = mask.reshape(F_all, *latents.shape[-2:])[shard.f0:shard.f0 + shard.local].contiguous()
         with self.progress_bar(total=n) as bar:
             for i, t in enumerate(ts):
                 if self.interrupt:
@@ -235,6 +258,11 @@ class CustomStableDiffusion3Pipeline:
                                      return_dict=False, joint_attention_kwargs={"idx": i})[0]
                 latents = self._euler_eta(latents, _f16(v[2 * F_:]), target, ds[i], eta_values[i], tl[i] / T)
                 bar.update()
+        if shard is not None:
+            latents = shard.gather_frames(latents)
+            if shard.rank != 0 and output_type != "latent":          # rank 0 decodes and writes
+                self.maybe_free_model_hooks()
+                return StableDiffusion3PipelineOutput(images=None) if return_dict else (None,)
         image = self._decode(latents, output_type)
         self.maybe_free_model_hooks()
         if not return_dict:

@@ -46,6 +46,7 @@ int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     UV_REQUIRE(h, "unet_create: out of host memory");
     h->impl.cfg = *cfg;
     if (const char* e = getenv("UNIVST_LN_FOLD")) h->impl.ln_fold = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    if (const char* e = getenv("UNIVST_CHAIN_BANDS")) h->impl.chain_bands = atoi(e) < 0 ? 0 : atoi(e);
     *out = h;
     return UV_OK;
 }
@@ -54,6 +55,11 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value) {
     if (!strcmp(name, "ln_fold")) {
         UV_REQUIRE(value >= 0 && value <= 2, "unet_set_option: ln_fold is 0, 1 or 2");
         h->impl.ln_fold = value;
+        return UV_OK;
+    }
+    if (!strcmp(name, "chain_bands")) {
+        UV_REQUIRE(value >= 0 && value <= 64, "unet_set_option: chain_bands is 0 (auto), 1 (off) or a band count <= 64");
+        h->impl.chain_bands = value;
         return UV_OK;
     }
     uv_set_error("unet_set_option: unknown option '%s'", name);
@@ -91,6 +97,7 @@ int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int
     h->impl.allreduce = ar;
     h->impl.kv_exchange = kv;
     h->impl.comm_user = user;
+    h->impl.native_comm = nullptr;          // callbacks (or none, world == 1: detached) replace a library communicator
     return UV_OK;
 }
 
@@ -258,6 +265,10 @@ int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* 
                            float thr, void* s) {
     UV_REQUIRE(key && now && fwd && bwd && acc, "warp_accumulate: null argument");
     return uv_launch_warp_accumulate(key, now, fwd, bwd, acc, Hh, W, thr, S(s));
+}
+int univst_warp_window_key(uint8_t* frames, const float* flows, int F, int Hh, int W, int key, int r, float thr, void* s) {
+    UV_REQUIRE(frames, "warp_window_key: null argument");
+    return uv_launch_warp_window_key(frames, flows, F, Hh, W, key, r, thr, S(s));
 }
 int univst_latent_window_smooth(void* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, void* s) {
     UV_REQUIRE(x0 && lflow, "latent_window_smooth: null argument");

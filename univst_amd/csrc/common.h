@@ -88,6 +88,30 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * (x + fmaf(-ax, pe, ax));            // 0.5 * (x + |x| * (1 - pe))
 }
 
+// x * gelu_erf(g) for TWO values per call, transcendental-free (round 4).  The GEGLU epilogue of the FF1 projections evaluates 40 960
+// GELUs per 256 x 320 tile with the matrix pipe idle (13.4 us of fixed cost per tile against 5.9 for a plain tile); the
+// A&S form above costs ~19 issue slots per value (rcp and exp2 take two each and nothing in it packs).  Here
+//     gelu(g) = 0.5 g (1 + S),  S = gc * Q(2 gc^2 / 25 - 1) ~= erf(gc / sqrt 2),  gc = clamp(g, -5, 5)
+// with Q the degree-12 Chebyshev fit of erf(sqrt(u/2)) / sqrt(u) on u in [0, 25] (|S - erf| <= 7.3e-7 incl. the clamp: 1 - erf(5/sqrt 2) =
+// 5.7e-7; |gelu error| <= 2e-6 absolute, three orders below fp16 resolution of the product that is stored).  Every operation is a
+// v_pk_fma_f32 / v_pk_mul_f32 on the pair plus one v_med3_f32 per value: 10 issue slots per value (ISA-counted).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 geglu_erf2(f2 x, f2 g) {
+    f2 gc;
+    gc.x = __builtin_amdgcn_fmed3f(g.x, -5.f, 5.f);
+    gc.y = __builtin_amdgcn_fmed3f(g.y, -5.f, 5.f);
+    const f2 s = __builtin_elementwise_fma(gc * 0.08f, gc, f2{-1.f, -1.f});
+    constexpr float c[13] = {2.827276369e-01f, -1.405918177e-01f, 1.030358595e-01f, -8.090256480e-02f, 6.295351729e-02f, -4.642625655e-02f,
+                             3.247217962e-02f, -2.261424982e-02f, 1.353305501e-02f, -5.053833458e-03f, 2.749192302e-03f, -3.353461957e-03f,
+                             1.470752778e-03f};
+    f2 p = f2{c[12], c[12]};
+#pragma unroll
+    for (int i = 11; i >= 0; --i) p = __builtin_elementwise_fma(p, s, f2{c[i], c[i]});
+    const f2 S = gc * p;
+    const f2 t = (x * 0.5f) * g;
+    return __builtin_elementwise_fma(t, S, t);
+}
+
 // XCD-aware bijective block remap (8 XCDs, block b observed on XCD b%8): consecutive logical ids
 // land on the same XCD so tiles that share an operand panel hit the same 4 MiB L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

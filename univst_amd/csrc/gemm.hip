@@ -92,11 +92,17 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                     const float* cc = cf + cn + i * 16 + g * 4;
                     const f4 wx = *reinterpret_cast<const f4*>(cc), wg = *reinterpret_cast<const f4*>(cc + 16);
                     const f4 cx = *reinterpret_cast<const f4*>(cc + EPC_LNB), cg = *reinterpret_cast<const f4*>(cc + EPC_LNB + 16);
+                    float xv[4], gv[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float xv = fmaf(ln.y, fmaf(-ln.x, wx[r], col[i][r]), cx[r]);
-                        const float gv = fmaf(ln.y, fmaf(-ln.x, wg[r], col[i + 1][r]), cg[r]);
-                        o[r] = (half_t)(xv * gelu_erf_f(gv));
+                        xv[r] = fmaf(ln.y, fmaf(-ln.x, wx[r], col[i][r]), cx[r]);
+                        gv[r] = fmaf(ln.y, fmaf(-ln.x, wg[r], col[i + 1][r]), cg[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        const f2 y = geglu_erf2(f2{xv[r], xv[r + 1]}, f2{gv[r], gv[r + 1]});
+                        o[r] = (half_t)y.x;
+                        o[r + 1] = (half_t)y.y;
                     }
                     *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + no) = o;
                     continue;
@@ -111,10 +117,11 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float xv = col[i][r] + (float)bx[r];
-                    float gv = col[i + 1][r] + (float)bg[r];
-                    o[r] = (half_t)(xv * gelu_erf_f(gv));
+                for (int r = 0; r < 4; r += 2) {
+                    const f2 y = geglu_erf2(f2{col[i][r] + (float)bx[r], col[i][r + 1] + (float)bx[r + 1]},
+                                            f2{col[i + 1][r] + (float)bg[r], col[i + 1][r + 1] + (float)bg[r + 1]});
+                    o[r] = (half_t)y.x;
+                    o[r + 1] = (half_t)y.y;
                 }
                 *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + no) = o;
             }
@@ -346,7 +353,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                 }
                 h8 o;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = (half_t)(xv[r] * gelu_erf_f(gv[r]));
+                for (int r = 0; r < 8; r += 2) {
+                    const f2 y = geglu_erf2(f2{xv[r], xv[r + 1]}, f2{gv[r], gv[r + 1]});
+                    o[r] = (half_t)y.x;
+                    o[r + 1] = (half_t)y.y;
+                }
                 *reinterpret_cast<h8*>(p.Y + (long)m * p.ldy + nb / 2 + cq * 8) = o;
             }
         }

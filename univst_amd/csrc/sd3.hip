@@ -434,7 +434,7 @@ int univst_sd3_adain_shift(void* qkv, int64_t ld, int F, int N, int C, int heads
 }
 
 int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin, int heads,
-                               int head_dim, int clip_length, int shift, int idx, float eta1, float eta2, float rms_eps, void* out_img,
+                               int head_dim, int clip_length, int shift, float beta, float rms_eps, void* out_img,
                                void* out_txt, const univst_sd3_gated_residual* gr, univst_comm* comm, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     UV_REQUIRE(w && hidden && out_img && B >= 1 && N >= 1 && heads >= 1, "sd3_joint_attention: null / empty argument");
@@ -480,8 +480,7 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         if (w->norm_q && w->norm_k) RUN(launch_rms_pair(qkv_i, 3 * C, rows_i, heads, head_dim, 0, H(w->norm_q), C, H(w->norm_k), rms_eps, s, presc ? qscale : 1.f));
         else if (w->norm_q) RUN(univst_rmsnorm_heads(qkv_i, 3 * C, rows_i, heads, head_dim, w->norm_q, rms_eps, s));
         else if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
-        if (shift && (float)idx >= eta1 * 50.f && (float)idx <= eta2 * 50.f) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0)
-            const float beta = (0.9f - 0.1f) / (eta1 * 50.f - eta2 * 50.f) * ((float)idx - eta2 * 50.f) + 0.1f;
+        if (shift) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0); window test + beta come from the caller, evaluated in double
             RUN(univst_sd3_adain_shift(qkv_i, 3 * C, Fb, N, C, heads, 0.8f, beta, 2.0f, st, s));
         }
         if (enc) {

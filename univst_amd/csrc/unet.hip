@@ -865,54 +865,77 @@ struct Fwd {
         ap.q_prescaled = qs;
         RUN(uv_launch_attention(ap, s));
         free(qkv);
+        // ---- the row-local chain behind the self-attention: to_out + residual -> (norm2) -> attn2 -> to_out + residual -> (norm3) ->
+        // GEGLU projection -> FF2 + residual.  Round 4: it runs BAND BY BAND over whole frames when the level is large (64x64 level of
+        // an unsharded clip: 196 608 rows, every C-wide tensor 126 MB, the 4C-wide hidden one 503 MB): with bands of 65 536 rows (one
+        // round of 256-row tiles on the 256 CUs) the band's intermediates (42 MB each, hidden 168 MB) are re-read by the next kernel of
+        // the chain while they are still in the 256 MB Infinity Cache instead of streaming from HBM, and the hidden buffer is
+        // band-sized (tools/bench_mall_bands.py: -13 % on the four FF linears; bit-identical results: every kernel is row-local).
+        const long N_rows = N;
+        int nbands = 1;
+        if (u.chain_bands != 1) {
+            const long target = 65536;
+            int want = u.chain_bands > 1 ? u.chain_bands : (int)(rows / target);
+            while (want > 1 && (x.imgs % want != 0 || (u.chain_bands <= 1 && rows / want < target))) --want;
+            nbands = want < 1 ? 1 : want;
+        }
+        const int band_imgs = x.imgs / nbands;
+        const long brows = (long)band_imgs * N_rows;
+        // (buffers are taken when first needed and, with ONE band, released as soon as the chain is past them — the arena's
+        // high-water mark of the unbanded graph is unchanged; with bands the full-height tensors live until the last band, the band-sized
+        // q2 / hidden buffers are reused by every band)
         half_t* h2 = alloc(rows * C);
-        if (!h2) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2, C, h, C, nullptr, 0, lnst));
-        free(h);
-        // ---- attn2 (text)
-        gm = W(b + ".norm2.weight"); bt = W(b + ".norm2.bias");
-        if (!gm || !bt) return u.missing_error();
-        if (!fold) RUN(uv_launch_layernorm(h2, C, t0, C, gm, bt, rows, C, 1e-5f, s));
-        half_t* q2 = alloc(rows * C);
         half_t* kv = alloc((long)B * text_len * 2 * C);
-        if (!q2 || !kv) return UV_ERR_STATE;
+        half_t *h3 = nullptr, *h4 = nullptr, *q2 = nullptr, *mid = nullptr;
+        if (!h2 || !kv) return UV_ERR_STATE;
+        half_t *gm2 = W(b + ".norm2.weight"), *bt2 = W(b + ".norm2.bias"), *gm3 = W(b + ".norm3.weight"), *bt3 = W(b + ".norm3.bias");
+        half_t* tb = W(b + ".attn_temporal.to_out.0.bias");
+        if (!gm2 || !bt2 || !gm3 || !bt3 || !tb) return u.missing_error();
         const bool qs2 = u.find(b + ".attn2.to_q.weight#qs") != nullptr;
         const std::string wq2 = b + (qs2 ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight");
-        if (fold) RUN(linear(h2, C, rows, C, wq2 + "#ln", "", C, q2, C, nullptr, 0, nullptr, 0, nullptr, lnst));
-        else RUN(linear(t0, C, rows, C, wq2, "", C, q2, C));
+        const bool t_attn = u.temporal_attn_active.count(b) != 0;
         RUN(linear(text, u.cfg.cross_attention_dim, (long)B * text_len, u.cfg.cross_attention_dim, b + ".attn2.kv#fused", "",
                    2 * C, kv, 2 * C));
-        ap.q = q2; ap.ldq = C;
-        ap.k = kv; ap.v = kv + C; ap.ldkv = 2 * C;
-        ap.o = t0; ap.ldo = C;
-        ap.src_idx = idx_text; ap.src_cnt = nullptr; ap.src_logw = nullptr; ap.nsrc = 1; ap.Nkv = text_len;
-        ap.q_prescaled = qs2;
-        RUN(uv_launch_attention(ap, s));
-        free(q2);
-        free(kv);
-        half_t* h3 = alloc(rows * C);
-        if (!h3) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3, C, h2, C, nullptr, 0, fold3 ? lnst : nullptr));
-        free(h2);
-        // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
-        gm = W(b + ".norm3.weight"); bt = W(b + ".norm3.bias");
-        if (!gm || !bt) return u.missing_error();
-        if (!fold3) RUN(uv_launch_layernorm(h3, C, t0, C, gm, bt, rows, C, 1e-5f, s));
-        half_t* mid = alloc(rows * 4 * C);
-        if (!mid) return UV_ERR_STATE;
-        if (lnst && !fold3) free(lnst);
-        if (fold3) {
-            RUN(linear(h3, C, rows, C, b + ".ff.net.0.proj.weight#geglu#ln", "", 8 * C, mid, 4 * C, nullptr, 0, nullptr, 1, nullptr, lnst));
-            free(lnst);
-        } else
-            RUN(linear(t0, C, rows, C, b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu", 8 * C, mid, 4 * C, nullptr,
-                       0, nullptr, 1));
-        half_t* tb = W(b + ".attn_temporal.to_out.0.bias");
-        if (!tb) return u.missing_error();
-        half_t* h4 = alloc(rows * C);
-        if (!h4) return UV_ERR_STATE;
-        const bool t_attn = u.temporal_attn_active.count(b) != 0;
-        RUN(linear(mid, 4 * C, rows, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", C, h4, C, h3, C, t_attn ? nullptr : tb));
+        for (int bd = 0; bd < nbands; ++bd) {
+            const long r0 = (long)bd * brows, o = r0 * C;
+            float* lb = lnst ? lnst + r0 * (C / 160) * 2 : nullptr;
+            RUN(linear(t0 + o, C, brows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2 + o, C, h + o, C, nullptr, 0, lb));
+            if (nbands == 1) free(h);
+            if (!q2 && !(q2 = alloc(brows * C))) return UV_ERR_STATE;
+            // ---- attn2 (text)
+            if (!fold) RUN(uv_launch_layernorm(h2 + o, C, t0 + o, C, gm2, bt2, brows, C, 1e-5f, s));
+            if (fold) RUN(linear(h2 + o, C, brows, C, wq2 + "#ln", "", C, q2, C, nullptr, 0, nullptr, 0, nullptr, lb));
+            else RUN(linear(t0 + o, C, brows, C, wq2, "", C, q2, C));
+            ap.q = q2; ap.ldq = C;
+            ap.k = kv; ap.v = kv + C; ap.ldkv = 2 * C;
+            ap.o = t0 + o; ap.ldo = C;
+            ap.src_idx = idx_text + bd * band_imgs; ap.src_cnt = nullptr; ap.src_logw = nullptr; ap.nsrc = 1; ap.Nkv = text_len;
+            ap.BF = band_imgs;
+            ap.q_prescaled = qs2;
+            RUN(uv_launch_attention(ap, s));
+            if (nbands == 1) { free(q2); free(kv); }
+            if (!h3 && !(h3 = alloc(rows * C))) return UV_ERR_STATE;
+            RUN(linear(t0 + o, C, brows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3 + o, C, h2 + o, C, nullptr, 0, fold3 ? lb : nullptr));
+            if (nbands == 1) free(h2);
+            if (!mid && !(mid = alloc(brows * 4 * C))) return UV_ERR_STATE;
+            // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
+            if (!fold3) {
+                RUN(uv_launch_layernorm(h3 + o, C, t0 + o, C, gm3, bt3, brows, C, 1e-5f, s));
+                RUN(linear(t0 + o, C, brows, C, b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu", 8 * C, mid, 4 * C, nullptr, 0, nullptr, 1));
+            } else {
+                RUN(linear(h3 + o, C, brows, C, b + ".ff.net.0.proj.weight#geglu#ln", "", 8 * C, mid, 4 * C, nullptr, 0, nullptr, 1, nullptr, lb));
+            }
+            if (nbands == 1 && lnst) free(lnst);
+            if (!h4 && !(h4 = alloc(rows * C))) return UV_ERR_STATE;
+            RUN(linear(mid, 4 * C, brows, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", C, h4 + o, C, h3 + o, C, t_attn ? nullptr : tb));
+        }
+        if (nbands > 1) {
+            free(h);
+            free(q2);
+            free(kv);
+            free(h2);
+            if (lnst) free(lnst);
+        }
         free(mid);
         free(h3);
         if (t_attn) {      // TRAINED temporal attention (attention.py:336-346): LayerNorm, q|k|v, softmax over the F frames of every pixel, to_out + residual

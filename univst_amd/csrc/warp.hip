@@ -52,6 +52,72 @@ __global__ __launch_bounds__(256) void warp_accumulate_kernel(const uint8_t* __r
     acc[p * 3 + 2] += (float)o[2];
 }
 
+// One launch per KEY FRAME (round 4; was 2r warp launches + accumulate + store = 58 launches of ~17 us per 16-frame pass): the window
+// mean of stable_diffusion.py:731-747 for key frame `key`, in place in the [F,H,W,3] working copy.  The (up to 2r) neighbours are
+// warped exactly as warp_accumulate_kernel does, the terms are added in the reference's order b = -r .. r (sums of <= 9 integers
+// <= 255 are exact in fp32 whatever the order), the mean is stored with the same float -> uint8 truncation.  A thread reads the key
+// frame only at its own pixel and gathers from OTHER frames, so writing est[key] in place is race-free.
+// flows: [nn][2][H][W][2] — (forward key -> now, backward now -> key) of the nn in-clip neighbours in increasing bias.
+__global__ __launch_bounds__(256) void warp_window_key_kernel(uint8_t* __restrict__ est, const float* __restrict__ flows, int F, int H, int W, int key,
+                                                              int r, float thr) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long HW = (long)H * W;
+    if (p >= HW) return;
+    const int y = (int)(p / W), x = (int)(p % W);
+    const float cx = (float)x, cy = (float)y;
+    uint8_t* kf = est + (long)key * HW * 3;
+    const int k0 = kf[p * 3], k1 = kf[p * 3 + 1], k2 = kf[p * 3 + 2];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    int weight = 0, slot = 0;
+    for (int b = -r; b <= r; ++b) {
+        const int nowi = key + b;
+        if (nowi < 0 || nowi >= F) continue;
+        ++weight;
+        if (b == 0) {
+            a0 += (float)k0; a1 += (float)k1; a2 += (float)k2;
+            continue;
+        }
+        const float* fwd = flows + (long)slot * 2 * HW * 2;
+        const float* bwd = fwd + HW * 2;
+        ++slot;
+        const uint8_t* now = est + (long)nowi * HW * 3;
+        const float fx = fwd[p * 2], fy = fwd[p * 2 + 1];
+        const float c1x = __fadd_rn(cx, fx), c1y = __fadd_rn(cy, fy);
+        const float ex = __fsub_rn(__fadd_rn(c1x, bwd[p * 2]), cx);
+        const float ey = __fsub_rn(__fadd_rn(c1y, bwd[p * 2 + 1]), cy);
+        const float err = __fsqrt_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)));
+        int o[3] = {k0, k1, k2};
+        if (!(err > thr)) {
+            int sx = __float2int_rn(__fmul_rn(c1x, 32.f));
+            int sy = __float2int_rn(__fmul_rn(c1y, 32.f));
+            int ix = sx >> 5, iy = sy >> 5;
+            ix = ix < -32768 ? -32768 : (ix > 32767 ? 32767 : ix);
+            iy = iy < -32768 ? -32768 : (iy > 32767 ? 32767 : iy);
+            const int ax = sx & 31, ay = sy & 31;
+            const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+            const bool x0 = ix >= 0 && ix < W, x1 = ix + 1 >= 0 && ix + 1 < W;
+            const bool y0 = iy >= 0 && iy < H, y1 = iy + 1 >= 0 && iy + 1 < H;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                int v00 = (y0 && x0) ? now[((long)iy * W + ix) * 3 + ch] : 0;
+                int v01 = (y0 && x1) ? now[((long)iy * W + ix + 1) * 3 + ch] : 0;
+                int v10 = (y1 && x0) ? now[((long)(iy + 1) * W + ix) * 3 + ch] : 0;
+                int v11 = (y1 && x1) ? now[((long)(iy + 1) * W + ix + 1) * 3 + ch] : 0;
+                int rr = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+                o[ch] = rr < 0 ? 0 : (rr > 255 ? 255 : rr);
+            }
+        }
+        a0 += (float)o[0]; a1 += (float)o[1]; a2 += (float)o[2];
+    }
+    const float wf = (float)weight;
+    const float m[3] = {__fdiv_rn(a0, wf), __fdiv_rn(a1, wf), __fdiv_rn(a2, wf)};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int t = (int)m[ch];
+        kf[p * 3 + ch] = (uint8_t)(t < 0 ? 0 : (t > 255 ? 255 : t));
+    }
+}
+
 __global__ void accumulate_u8_kernel(const uint8_t* __restrict__ f, float* __restrict__ acc, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) acc[i] += (float)f[i];
@@ -131,6 +197,13 @@ int uv_launch_warp_accumulate(const uint8_t* key, const uint8_t* now, const floa
                               float thr, hipStream_t s) {
     hipLaunchKernelGGL(warp_accumulate_kernel, dim3((unsigned)(((long)H * W + 255) / 256)), dim3(256), 0, s, key, now, fwd, bwd, acc,
                        H, W, thr);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+int uv_launch_warp_window_key(uint8_t* est, const float* flows, int F, int H, int W, int key, int r, float thr, hipStream_t s) {
+    UV_REQUIRE(est && F >= 1 && key >= 0 && key < F && r >= 1 && r <= 8 && H >= 1 && W >= 1, "warp_window_key: bad geometry (F=%d key=%d r=%d)", F, key, r);
+    UV_REQUIRE(flows || F == 1, "warp_window_key: flows missing");
+    hipLaunchKernelGGL(warp_window_key_kernel, dim3((unsigned)(((long)H * W + 255) / 256)), dim3(256), 0, s, est, flows, F, H, W, key, r, thr);
     UV_LAUNCH_CHECK();
     return UV_OK;
 }

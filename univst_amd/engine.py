@@ -68,7 +68,7 @@ def _dev16(t, device):
 def transfer_loop(pipe, latents: torch.Tensor, text3: torch.Tensor, content_inv: Sequence[torch.Tensor],
                   style_inv: Sequence[torch.Tensor], mask_u8: Optional[torch.Tensor], num_inference_steps: int = 50,
                   smoother: Optional[Callable] = None, callback: Optional[Callable] = None,
-                  skip_dead_branches: bool = False) -> torch.Tensor:
+                  skip_dead_branches: bool = False, shard=None) -> torch.Tensor:
     """stable_diffusion.py:680-766 of the reference, device-resident.
 
     pipe            object with ``.unet`` (native UNetPseudo3DConditionModel) and ``.scheduler``
@@ -80,19 +80,31 @@ def transfer_loop(pipe, latents: torch.Tensor, text3: torch.Tensor, content_inv:
     skip_dead_branches  run only the stylised branch once the PnP window is closed (idx > eta2*50): branches
                     0/1 no longer influence branch 2 and their eps is discarded (:712) — identical output,
                     2/3 less work on those steps.  Off by default (reference-equivalent work).
+    shard           optional ``parallel.FrameShard`` already attached to ``pipe.unet`` (one process per GPU):
+                    every argument is the FULL clip on every rank; this rank runs its frames of all three branches and the
+                    full stylised latents come back on every rank (all-gather at the end).  The smoother is sequential over
+                    frames (Gauss-Seidel over key frames): on its five steps the clip is gathered, smoothed by every rank
+                    (replicas) and re-sliced.
     """
     sched, unet = pipe.scheduler, pipe.unet
     dev = latents.device
     n = num_inference_steps
     sched.set_timesteps(n)
-    latents = _dev16(latents, dev)
+    sharded = shard is not None and shard.world > 1
+    if sharded and latents.shape[2] != shard.frames:
+        raise ValueError(f"transfer_loop: the shard was built for {shard.frames} frames, the clip has {latents.shape[2]}")
+    cut = shard.slice_frames if sharded else (lambda t: t)
+    latents = cut(_dev16(latents, dev))
     text3 = _dev16(text3, dev)
-    cinv = [_dev16(t, dev) for t in content_inv]
-    sinv = [_dev16(t, dev) for t in style_inv]
+    cinv = [cut(_dev16(t, dev)) for t in content_inv]
+    sinv = [cut(_dev16(t, dev)) for t in style_inv]
+    adain = shard.latent_adain if sharded else latent_adain
     m = None
     if mask_u8 is not None:
         mk = mask_u8.to(dev).to(torch.uint8).reshape(-1, *mask_u8.shape[-2:]).contiguous()
         m = _native.mask_resize(mk, latents.shape[-2], latents.shape[-1])
+        if sharded:
+            m = m.reshape(-1, latents.shape[-2], latents.shape[-1])[shard.f0:shard.f0 + shard.local].contiguous()
     eta2 = 0.5
     if skip_dead_branches:
         register_time(pipe, 0)
@@ -104,7 +116,7 @@ def transfer_loop(pipe, latents: torch.Tensor, text3: torch.Tensor, content_inv:
         if m is not None and i <= 0.9 * n:
             latents = _native.mask_blend(latents, c_t, m)
         if i > 0.8 * n and i <= 0.9 * n:
-            latents = _native.mask_blend(latent_adain(latents, s_t), c_t, m)
+            latents = _native.mask_blend(adain(latents, s_t), c_t, m)
         register_time(pipe, i)
         if skip_dead_branches and i > eta2 * 50:
             eps = _unet_single_branch(unet, latents, t, text3[2:3])
@@ -112,11 +124,14 @@ def transfer_loop(pipe, latents: torch.Tensor, text3: torch.Tensor, content_inv:
             x = torch.cat([c_t, s_t, latents])
             eps = unet(x, t, encoder_hidden_states=text3).sample[2:3]
         if smoother is not None and 20 <= i < 25:
-            eps = smoother(i, t, latents, eps)
+            if sharded:
+                eps = cut(smoother(i, t, shard.gather_frames(latents), shard.gather_frames(eps.contiguous())))
+            else:
+                eps = smoother(i, t, latents, eps)
         latents = ddim_step(sched, eps, t, latents)
         if callback is not None:
             callback(i, sched.timesteps[i], latents)
-    return latents
+    return shard.gather_frames(latents) if sharded else latents
 
 
 def _unet_single_branch(unet, latents, t, text1):

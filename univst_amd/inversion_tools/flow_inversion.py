@@ -29,7 +29,7 @@ def _invert_and_reconstruct(pipe, img_latents, inversion_path, reconstruction_pa
         images = pipe.reconstruction(prompt="", img_latents=img_latents, inversed_latents=inv, eta_base=0.85, eta_trend="constant", start_step=25,
                                      end_step=39, guidance_scale=1.0, DTYPE=weight_dtype, num_inference_steps=time_steps)
         from ..src.util import save_images_as_mp4
-        save_images_as_mp4(images, os.path.join(reconstruction_path, name))      # diffusers.utils.export_to_video(fps=8) in the reference
+        save_images_as_mp4(images, os.path.join(reconstruction_path, name), fps=8)      # diffusers.utils.export_to_video(fps=8) in the reference
     return inv
 
 
@@ -109,7 +109,9 @@ def rf_solver(pipeline, image_latents, prompt="", num_inference_steps=50, invers
             v = _velocity(pipeline, z, 1000 * t_curr, pe, pp, idx, ft_indices, ft_timesteps, ft_path)
             dt = t_prev - t_curr
             mid = _native.axpby(z, v, 1.0, dt / 2)
-            v_mid = _velocity(pipeline, mid, 1000 * (t_curr + dt / 2), pe, pp, idx, ft_indices, ft_timesteps, ft_path)
+            # the midpoint evaluation takes NO ft_* arguments (flow_inversion.py:242-249): the dumped feature map is that of the first
+            # evaluation (hidden state at t_curr), not overwritten by the midpoint's
+            v_mid = _velocity(pipeline, mid, 1000 * (t_curr + dt / 2), pe, pp, idx, None, None, None)
             c = (0.5 * dt ** 2) / (dt / 2)
             z = _native.axpbypcz(z, v, v_mid, 1.0, dt - c, c)
             _save(inversion_path, idx + 1, z.to(dt_in))

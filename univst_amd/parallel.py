@@ -34,6 +34,64 @@ import torch
 from . import _native
 
 
+def init_distributed(backend: Optional[str] = None, timeout_s: int = 300):
+    """One process per GPU, started by ``torchrun --nproc-per-node N`` (or ``python -m torch.distributed.run``): read
+    RANK / WORLD_SIZE / LOCAL_RANK, bind this process to its GPU and join the process group (backend "nccl" = RCCL on ROCm;
+    ``UNIVST_DIST_BACKEND`` / ``backend`` override it, e.g. "gloo" when several ranks share one GPU during bring-up).
+    Returns (rank, world).  Without the launcher environment (a plain ``python run_video_style_transfer_sd.py``): (0, 1) and
+    nothing is initialised — the single-GPU path is untouched."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import datetime
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available():
+        torch.cuda.set_device(min(local, torch.cuda.device_count() - 1))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or os.environ.get("UNIVST_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {"timeout": datetime.timedelta(seconds=timeout_s)}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def dist_rank_world():
+    """(rank, world) of the default process group; (0, 1) when torch.distributed is not initialised."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:       # noqa: BLE001
+        pass
+    return 0, 1
+
+
+def auto_frame_shard(pipe, frames: int, latent_hw, check_inputs=None, branches: int = 3, log=print):
+    """The frame shard of ``pipe.unet`` for the current process group, built (and checked) once per pipeline and geometry: None
+    when there is one process; otherwise a ``FrameShard`` attached to the UNet whose communicator passed ``self_check`` (library IPC
+    first, ``torch.distributed`` callbacks as the fall-back).  ``check_inputs`` = (content [1,4,F,h,w], style, text3) for the check."""
+    rank, world = dist_rank_world()
+    if world <= 1:
+        return None
+    key = (rank, world, frames, tuple(latent_hw))
+    cache = pipe.__dict__.setdefault("_univst_shards", {})
+    if key in cache:
+        return cache[key]
+    h, w = latent_hw
+    shard = FrameShard(rank, world, frames)
+    shard.attach(pipe.unet, max_tokens=h * w, branches=branches)
+    if check_inputs is not None:
+        rep = shard.self_check(pipe, *check_inputs)
+        if rank == 0 and log is not None:
+            log(f"[univst_amd] frame shard over {world} GPUs: {rep}")
+    cache[key] = shard
+    pipe.shard_report = getattr(shard, "report", None)
+    return shard
+
+
 class FrameShard:
     def __init__(self, rank: int, world: int, frames: int, comm=None):
         if frames % world != 0:
@@ -128,6 +186,79 @@ class FrameShard:
                       "unet_set_comm")
         self._tokens, self._handle = tokens, handle
 
+    # ------------------------------------------------------------------ the sharded path checked against the unsharded one
+    def detached(self, unet):
+        """context manager: ``unet`` runs UNSHARDED (world 1, whole clips) inside the block, e.g. as the reference of
+        ``self_check``; the hooks are put back on exit."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if self.world == 1:
+                yield
+                return
+            unet._sync_native()
+            unet._frame_shard = None
+            _native.check(_native.load().univst_unet_set_comm(unet._native_handle, 0, 1, None, 0, None, None, None), "unet_set_comm(detach)")
+            try:
+                yield
+            finally:
+                unet._frame_shard = self
+                self._handle = None          # re-register on the next forward
+                self.ensure(unet, max(self._tokens, 1))
+        return cm()
+
+    def self_check(self, pipe, content_full, style_full, text3, idx: int = 10, t: int = 781, tol: float = 2e-2) -> dict:
+        """Every rank compares ONE frame-sharded three-branch forward inside the PnP window (K/V exchange + all 45 GroupNorm
+        all-reduces) with the unsharded forward of the same UNet on the whole clip, before anything that matters runs through the
+        communicator.  A communicator that fails — wrong numbers, a refused IPC mapping, a bounded wait that gave up — is replaced
+        (library IPC -> torch.distributed callbacks) on ALL ranks together; if that one fails too a RuntimeError carries both errors.
+        Returns (and keeps in ``self.report``) {"comm", "max_rel_err_vs_unsharded"[, "rejected"]}.  A collective: call on all ranks."""
+        if self.world == 1:
+            self.report = {"comm": None, "max_rel_err_vs_unsharded": 0.0}
+            return self.report
+        import torch.distributed as dist
+        from .backbones.video_diffusion_sd.pnp_utils import register_time
+        unet = pipe.unet
+        registered = _pnp_registered(unet)
+        mix = (0.5 * (content_full.float() + style_full.float())).to(torch.float16)
+        xf = torch.cat([content_full.to(torch.float16), style_full.to(torch.float16), mix]).contiguous()
+        text3 = text3.to(torch.float16).contiguous()
+        with self.detached(unet):
+            if registered:
+                register_time(pipe, idx)
+            want = unet(xf, t, encoder_hidden_states=text3).sample[:, :, self.f0:self.f0 + self.local].float()
+
+        def once():
+            try:
+                if registered:
+                    register_time(pipe, idx)
+                got = unet(self.slice_frames(xf), t, encoder_hidden_states=text3).sample.float()
+                torch.cuda.synchronize()
+                err = float((got - want).abs().max() / want.abs().max())
+            except Exception as e:      # noqa: BLE001  (a failed collective surfaces as RuntimeError out of the native call)
+                err = float("inf")
+                print(f"[univst_amd] rank {self.rank}: sharded self-check raised {type(e).__name__}: {e}", flush=True)
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err)
+            return max(errs)
+
+        err = once()
+        kind = type(self.comm).__name__
+        self.report = {"comm": kind, "max_rel_err_vs_unsharded": err}
+        if not err < tol:
+            if self.rank == 0:
+                print(f"[univst_amd] frame-sharded forward through {kind} differs from the unsharded one (max rel err {err}); "
+                      "switching to the torch.distributed callbacks", flush=True)
+            self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
+            self._handle, self._tokens, self.ws = None, 0, None
+            self.ensure(unet, xf.shape[-1] * xf.shape[-2])
+            err2 = once()
+            self.report = {"comm": type(self.comm).__name__, "max_rel_err_vs_unsharded": err2, "rejected": {"comm": kind, "max_rel_err": err}}
+            if not err2 < tol:
+                raise RuntimeError(f"frame-sharded forward is wrong through both communicators ({kind}: {err}, {type(self.comm).__name__}: {err2})")
+        return self.report
+
     def _ws_bytes(self, unet, tokens: int, slots: int = 6) -> int:
         """64 KiB (GroupNorm partials) + `slots` K|V packs of a `tokens`-token latent: the largest pack is B * N * 2C fp16 over the
         attention levels (N shrinks 4x per level while C grows <= 2x)."""
@@ -178,6 +309,13 @@ class FrameShard:
             eps = pipe.unet(x, t, encoder_hidden_states=text3).sample[2:3]
             return engine.ddim_step(pipe.scheduler, eps, t, latents)
         return step
+
+
+def _pnp_registered(unet) -> bool:
+    """register_spatial_attention_pnp was applied to this UNet (whether or not register_time has run yet)."""
+    from .backbones.video_diffusion_sd.pnp_utils import PNP_LAYERS
+    return any(getattr(unet.up_blocks[r].attentions[b].transformer_blocks[0].attn1, "_univst_native_pnp", False)
+               for r, bs in PNP_LAYERS.items() for b in bs)
 
 
 class Sd3FrameShard:
@@ -245,6 +383,16 @@ class NativeIpcComm:
         dist.all_gather_object(out, blob)
         return out
 
+    def _agree(self, ok: bool, what: str, payload: bytes = b""):
+        """host-side agreement: every rank learns whether EVERY rank got through `what`; if one did not, all raise
+        together — so the fall-back to the torch.distributed callbacks happens on all ranks at once instead of the healthy
+        ranks spinning in a device-side collective their failed peer never joins.  Returns the peers' payloads."""
+        blobs = self._exchange((b"\x01" if ok else b"\x00") + payload)
+        bad = [r for r, b in enumerate(blobs) if not b or b[0] != 1]
+        if len(blobs) != self.world or bad:
+            raise RuntimeError(f"IPC communicator: {what} failed on rank(s) {bad if bad else '?'} (this rank: {'ok' if ok else 'FAILED'})")
+        return [b[1:] for b in blobs]
+
     def _build(self, ws_bytes: int):
         lib = _native.load()
         if self.ptr is not None:
@@ -252,22 +400,42 @@ class NativeIpcComm:
             lib.univst_comm_destroy(self.ptr)
             self.ptr = None
         h = C.c_void_p()
-        _native.check(lib.univst_comm_create(self.rank, self.world, int(ws_bytes), C.byref(h)), "comm_create")
-        self.ptr, self.ws_bytes = h, int(ws_bytes)
         nb = lib.univst_comm_handle_bytes()
         mine = C.create_string_buffer(nb)
-        _native.check(lib.univst_comm_export(h, mine), "comm_export")
-        blobs = self._exchange(mine.raw)
-        if len(blobs) != self.world or any(len(b) != nb for b in blobs):
+        err = None
+        try:
+            _native.check(lib.univst_comm_create(self.rank, self.world, int(ws_bytes), C.byref(h)), "comm_create")
+            _native.check(lib.univst_comm_export(h, mine), "comm_export")
+        except Exception as e:       # noqa: BLE001
+            err = e
+        try:
+            blobs = self._agree(err is None, "create/export", mine.raw)
+        except RuntimeError as e:
+            if h:
+                lib.univst_comm_destroy(h)
+            raise e from err
+        if any(len(b) != nb for b in blobs):
+            lib.univst_comm_destroy(h)
             raise RuntimeError("IPC handle exchange returned a malformed list")
-        _native.check(lib.univst_comm_connect(h, b"".join(blobs)), "comm_connect")
-        # self-test (a collective): sum of (rank + 1) * (i + 1) must come out exactly, on every rank
-        t = torch.arange(1, 65, device=self.device, dtype=torch.float32) * (self.rank + 1)
-        self.all_reduce_sum(t)
-        torch.cuda.synchronize()
-        want = torch.arange(1, 65, dtype=torch.float32) * (self.world * (self.world + 1) // 2)
-        if lib.univst_comm_status(h) or not torch.equal(t.cpu(), want):
-            raise RuntimeError(f"IPC all-reduce self-test failed on rank {self.rank} (status {lib.univst_comm_status(h)})")
+        self.ptr, self.ws_bytes = h, int(ws_bytes)
+        try:
+            _native.check(lib.univst_comm_connect(h, b"".join(blobs)), "comm_connect")
+        except Exception as e:       # noqa: BLE001
+            err = e
+        try:
+            self._agree(err is None, "hipIpcOpenMemHandle / connect")
+            # self-test (a device-side collective, entered only when every rank is connected): sum of (rank + 1) * (i + 1) must
+            # come out exactly, on every rank — and the ranks agree on THAT outcome too before anyone relies on the communicator
+            t = torch.arange(1, 65, device=self.device, dtype=torch.float32) * (self.rank + 1)
+            self.all_reduce_sum(t)
+            torch.cuda.synchronize()
+            want = torch.arange(1, 65, dtype=torch.float32) * (self.world * (self.world + 1) // 2)
+            st = lib.univst_comm_status(h)
+            self._agree(st == 0 and torch.equal(t.cpu(), want), f"all-reduce self-test (status {st} on rank {self.rank})")
+        except RuntimeError as e:
+            lib.univst_comm_destroy(h)
+            self.ptr = None
+            raise e from err
 
     def ensure_bytes(self, ws_bytes: int):
         """grow the shared workspace (a collective: every rank sees the same latent sizes, hence the same growth sequence)."""

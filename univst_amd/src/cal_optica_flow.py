@@ -79,28 +79,24 @@ def get_warp(image1_path, image2_path, ref_image1=None, ref_image2=None, occlusi
 def sliding_window_smooth(frames, flow_fn, mask01=None, r=2):
     """stable_diffusion.py:723-751.  frames uint8 [1,3,F,H,W] (device), mask01 uint8 [F,H,W] in {0,1}
     (1 = keep the original pixel).  Gauss-Seidel over key frames like the reference (key k sees the already
-    smoothed k-2, k-1), so frames are processed sequentially; each (key, neighbour) pair is one fused
-    occlusion + cv2-exact remap + accumulate launch."""
+    smoothed k-2, k-1), so frames are processed sequentially; each key frame is ONE launch (occlusion test + remap of
+    its up to 2r neighbours + window mean, csrc/warp.hip ``warp_window_key_kernel``; 16 launches per 16-frame pass, 58 before)."""
     lib = _native.load()
     b, c, F_, H, W = frames.shape
     assert b == 1 and c == 3
     est = frames[0].permute(1, 2, 3, 0).contiguous()            # [F,H,W,3] working copy (HWC like the reference's frames)
     ori = est.clone()
-    n = H * W * 3
     for key in range(F_):
-        acc = torch.zeros(H, W, 3, dtype=torch.float32, device=frames.device)
-        key_frame = est[key].clone()
-        weight = 0
-        for bias in range(-r, r + 1):
-            now = key + bias
-            if 0 <= now < F_:
-                if bias == 0:
-                    _native.check(lib.univst_accumulate_u8(est[now].data_ptr(), acc.data_ptr(), n, _native.stream_ptr()), "accumulate")
-                else:
-                    now_frame = est[now]
-                    warp_accumulate_(acc, key_frame, now_frame, flow_fn(key_frame, now_frame), flow_fn(now_frame, key_frame))
-                weight += 1
-        _native.check(lib.univst_window_store(acc.data_ptr(), float(weight), est[key].data_ptr(), n, _native.stream_ptr()), "window_store")
+        # the flows of this key frame against its in-clip neighbours (RAFT stand-in; estimated on the CURRENT working copy like the
+        # reference: frames k-2, k-1 are already smoothed), then ONE launch: warp every neighbour, add the key frame, store the mean
+        nbrs = [key + bias for bias in range(-r, r + 1) if bias != 0 and 0 <= key + bias < F_]
+        flows = None
+        if nbrs:
+            key_frame = est[key]
+            flows = torch.stack([torch.stack([flow_fn(key_frame, est[n]).to(torch.float32), flow_fn(est[n], key_frame).to(torch.float32)])
+                                 for n in nbrs]).contiguous()
+        _native.check(lib.univst_warp_window_key(est.data_ptr(), None if flows is None else flows.data_ptr(), F_, H, W, key, r, 1.5,
+                                                 _native.stream_ptr()), "warp_window_key")
     if mask01 is not None:
         m = mask01.to(torch.bool)[..., None]
         est = torch.where(m, ori, est)

@@ -12,6 +12,8 @@ from ..util import load_ddim_latents_at_t, seed_everything
 
 
 def main(a):
+    from ...parallel import init_distributed
+    init_distributed()            # torchrun --nproc-per-node N: the pipeline shards the frames over the N GPUs; rank 0 writes the PNGs
     if a.seed is not None:
         seed_everything(a.seed)
     pipe = build_pipeline(a.pretrained_model_path, a.weight_dtype)
@@ -22,7 +24,10 @@ def main(a):
     register_spatial_attention_pnp(pipe)
     samples = pipe.video_style_transfer("", latents=content_inv_noises, img_latents=content_inv_latents, num_inference_steps=a.time_steps,
                                         content_inv_path=a.content_inv_path, style_inv_path=a.style_inv_path, mask_path=a.mask_path,
-                                        eta_base=0.85, eta_trend="constant", start_step=25, end_step=39).images
+                                        eta_base=0.85, eta_trend="constant", start_step=25, end_step=39,
+                                        shard=False if a.no_shard else None).images
+    if samples is None:
+        return
     out = os.path.join(a.output_path, "sd3", f"{a.content_inv_path.split('/')[-2]}_{a.style_inv_path.split('/')[-2]}")
     os.makedirs(out, exist_ok=True)
     for idx, sample in enumerate(samples):
@@ -37,6 +42,7 @@ def parser():
     p.add_argument("--style_inv_path", type=str, default="results/styles-inv/sd3/00033/inversion")
     p.add_argument("--mask_path", type=str, default="results/masks/sd3/mallard-fly")
     p.add_argument("--output_path", type=str, default="output/")
+    p.add_argument("--no_shard", action="store_true", help="under torchrun: keep every rank on the whole clip (no frame sharding)")
     return p
 
 

@@ -56,19 +56,20 @@ def save_videos_grid(videos: torch.Tensor, path: str, rescale=False, n_rows=4, f
         ims[0].save(os.path.splitext(path)[0] + ".gif", save_all=True, append_images=ims[1:], duration=int(1000 / fps), loop=0)
 
 
-def save_images_as_mp4(images, save_path: str) -> None:
-    """util.py:50-60 (10 fps; mp4 through imageio when available, else an animated GIF next to the requested name, like
-    save_videos_grid)."""
+def save_images_as_mp4(images, save_path: str, fps: int = 10) -> None:
+    """util.py:50-60 (10 fps there; ``fps`` lets the SD3 inversion previews keep the 8 fps of the reference's
+    diffusers.utils.export_to_video call; mp4 through imageio when available, else an animated GIF next to the requested name,
+    like save_videos_grid)."""
     frames = [np.array(i.convert("RGB")) for i in images]
     try:
         import imageio
-        w = imageio.get_writer(save_path, fps=10)
+        w = imageio.get_writer(save_path, fps=fps)
         for f in frames:
             w.append_data(f)
         w.close()
     except ImportError:
         ims = [Image.fromarray(f) for f in frames]
-        ims[0].save(os.path.splitext(save_path)[0] + ".gif", save_all=True, append_images=ims[1:], duration=100, loop=0)
+        ims[0].save(os.path.splitext(save_path)[0] + ".gif", save_all=True, append_images=ims[1:], duration=int(round(1000 / fps)), loop=0)
 
 
 def load_image(image, convert_method=None, image_size=None):
