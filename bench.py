@@ -19,7 +19,7 @@ masks blended on steps 0..45).  --workload selects the other driver-timed lines 
   inversion         BASELINE config 2: the single-branch DDIM inversion loop (one step = one single-branch UNet call + next_step)
   inversion_pair    the content + style inversions of one job as one batch-2 trajectory (value = frames of BOTH clips / s)
   maskprop          point-matching mask propagation of a 16-frame clip (64x64x640 features, 256 classes, 512^2 masks); HBM-bound
-  warp              one sliding-window smoothing pass over 16 x 512^2 frames (58 occlusion + remap + blend launches); HBM-bound
+  warp              one sliding-window smoothing pass over 16 x 512^2 frames (58 occlusion + remap + blend warps in 16 launches, one per key frame); HBM-bound
 """
 import argparse
 import json
@@ -54,7 +54,8 @@ def parse():
     ap.add_argument("--model", default="sd15", choices=["sd15", "sd21"], help="UNet configuration: SD-v1.5 (headline) or the SD-v2.1 layout "
                                                                             "(Linear projections, head_dim 64, 1024-wide text states; SURVEY §8f-3)")
     ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
-                                                             "(no extrapolation in F; ~2 min on 16 threads) instead of F=2")
+                                                             "(no extrapolation in F; ~2 min on 16 threads); default: one step at the full count")
+    ap.add_argument("--quick-cpu", action="store_true", help="cpu_baseline: the F=2 sample of rounds 1-3 (14 s, extrapolated x8 in F)")
     ap.add_argument("--selftest-launch", action="store_true", help="multi-rank plumbing only (rendezvous, barriers, MAX over ranks, one JSON "
                                                                     "line); no GPU work, runs on a CPU box with --backend gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,11 +105,14 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(frames_full, unet=None, full=False, single_branch=False):
+def cpu_baseline(frames_full, unet=None, full=False, single_branch=False, quick=False):
     """oracle ('port' of the reference algorithm, fp32 PyTorch CPU ops, reference plumbing incl. the dead temporal
-    ops) on this box's host cores: TWO UNet steps (one inside the PnP window, one outside) at F=2 of the clip's frames —
-    extrapolated linearly in F (sparse-causal attention / convs / norms are all frame-linear) — or, with --full-cpu, at
-    the full frame count; then weighted to the 26 + 24 steps of the loop.  single_branch: the inversion step (no PnP)."""
+    ops) on this box's host cores, weighted to the 26 in-window + 24 out-of-window steps of the loop.
+    default: ONE three-branch UNet step inside the PnP window MEASURED at the full frame count (about a minute on 16 threads; no
+             extrapolation in F: the F = 2 sample of rounds 1-3 over-estimated the CPU by 15-50 %, its activations being cache-resident),
+             the out-of-window step taken as that time x the ratio of the two kinds of step measured at F = 2 (7 s each);
+    full (--full-cpu): both steps measured at the full frame count;  quick (--quick-cpu): both at F = 2, extrapolated linearly in F.
+    single_branch: the inversion step (no PnP)."""
     from oracle import unet_ref, synth_inputs as si
     cores = usable_cores()
     torch.set_num_threads(cores)
@@ -118,41 +122,46 @@ def cpu_baseline(frames_full, unet=None, full=False, single_branch=False):
         sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     else:
         sd = unet_ref.synth_state_dict(cfg, seed=33)
-    F_s = frames_full if full else 2
-    if single_branch:
-        x = si.content_latent(40, F_s, 64, 64)
-        ctx = si.text_embedding(768)
-    else:
-        x = torch.cat([si.content_latent(40, F_s, 64, 64), si.style_latent(40, F_s, 64, 64), si.content_latent(39, F_s, 64, 64)])
-        ctx = si.text_embedding(768).expand(3, -1, -1).contiguous()
-    with torch.no_grad():      # untimed warm-up (thread pool, allocator, oneDNN primitive caches): the first CPU step used to be 20 % slow
-        xw = x[:, :, :1].contiguous()
-        unet_ref.unet_forward(sd, cfg, xw, 781, ctx, pnp_idx=None if single_branch else 10, exact_temporal=True)
-    t1 = time.time()
-    with torch.no_grad():
-        unet_ref.unet_forward(sd, cfg, x, 781, ctx, pnp_idx=None if single_branch else 10, exact_temporal=True)   # inside the PnP window
-        t2 = time.time()
+
+    def inputs(F_s):
         if single_branch:
-            t_in, t_out = t2 - t1, t2 - t1
-        else:
-            unet_ref.unet_forward(sd, cfg, x, 381, ctx, pnp_idx=30, exact_temporal=True)     # a step outside it
-            t_in, t_out = t2 - t1, time.time() - t2
-    # the 50-step loop has 26 steps inside the window (i = 0..25) and 24 outside; per-step cost has no other data dependence
-    loop_full = (26 * t_in + 24 * t_out) * frames_full / F_s
+            return si.content_latent(40, F_s, 64, 64), si.text_embedding(768)
+        return (torch.cat([si.content_latent(40, F_s, 64, 64), si.style_latent(40, F_s, 64, 64), si.content_latent(39, F_s, 64, 64)]),
+                si.text_embedding(768).expand(3, -1, -1).contiguous())
+
+    def step(x, ctx, inside):
+        t = time.time()
+        with torch.no_grad():
+            unet_ref.unet_forward(sd, cfg, x, 781 if inside else 381, ctx, pnp_idx=None if single_branch else (10 if inside else 30), exact_temporal=True)
+        return time.time() - t
+
+    x2, ctx = inputs(2)
+    step(x2[:, :, :1].contiguous(), ctx, True)      # untimed warm-up (thread pool, allocator, oneDNN primitive caches): the first CPU step used to be 20 % slow
+    t1 = time.time()
     what = "single-branch UNet step (inversion)" if single_branch else "three-branch UNet steps (one inside the PnP window, one outside)"
-    note = None
-    if not full and not single_branch:      # the measured full-frame-count figure of record (python bench.py --full-cpu), if one is committed
-        try:
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("round") and f.endswith("_bench_fullcpu.json"))
-            rec = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["cpu_baseline"]
-            note = (f"measured without extrapolation (--full-cpu, profiles/{cands[-1]}): {rec['value']:.5f} frames/s on {rec['cores']} threads; "
-                    "the F=2 sample over-estimates the CPU (cache-resident activations)")
-        except Exception:
-            pass
-    return dict(value=frames_full / loop_full, unit="frames/s", cores=cores, kind="port", extrapolated=not full, note=note,
-                sample=f"{1 if single_branch else 2} {what}: {t_in:.1f} s / {t_out:.1f} s; fp32, all temporal ops, at F={F_s} of "
-                       f"{frames_full} frames, 64x64 latents, on {cores} threads (cgroup quota); "
-                       + ("" if full else f"EXTRAPOLATED x{frames_full // F_s} in F and ") + f"weighted to 26 + 24 steps (weight copy {t1 - t0:.0f} s excluded)")
+    if full or quick:
+        F_s = frames_full if full else 2
+        x, ctx = inputs(F_s)
+        t_in = step(x, ctx, True)
+        t_out = t_in if single_branch else step(x, ctx, False)
+        scale = frames_full / F_s
+        how = (f"{1 if single_branch else 2} {what}: {t_in:.1f} s / {t_out:.1f} s at F={F_s} of {frames_full} frames"
+               + ("" if full else f", EXTRAPOLATED x{frames_full // F_s} in F"))
+        extrap = not full
+    else:
+        a_in = step(x2, ctx, True)
+        ratio = 1.0 if single_branch else step(x2, ctx, False) / a_in
+        x, ctx = inputs(frames_full)
+        t_in = step(x, ctx, True)
+        t_out, scale = t_in * ratio, 1.0
+        how = (f"one {'single-branch' if single_branch else 'three-branch'} UNet step inside the PnP window MEASURED at the full F={frames_full}: {t_in:.1f} s; "
+               f"the out-of-window step taken as x{ratio:.3f} (ratio of the two kinds of step at F=2: {a_in:.1f} s in-window)")
+        extrap = False
+    # the 50-step loop has 26 steps inside the window (i = 0..25) and 24 outside; per-step cost has no other data dependence
+    loop_full = (26 * t_in + 24 * t_out) * scale
+    return dict(value=frames_full / loop_full, unit="frames/s", cores=cores, kind="port", extrapolated=extrap,
+                sample=f"{how}; fp32, all temporal ops, 64x64 latents, on {cores} threads (cgroup quota); weighted to 26 + 24 steps "
+                       f"(weight copy {t1 - t0:.0f} s excluded)")
 
 
 def hbm_roofline(kernel, algorithmic_bytes, ms, launches):
@@ -218,9 +227,10 @@ def run_aux_workload(a, dev):
            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.workload == "maskprop" else "u8", "data": "synthetic",
            "config": dict(out_cfg, workload=("maskprop_16x64x64x640_256cls_512sq" if a.workload == "maskprop" else "sliding_window_warp_blend_16x512x512_r2"))}
     if a.workload == "warp":
-        out["roofline"] = hbm_roofline("warp_accumulate_kernel (occlusion test + fixed-point remap + blend, 58 launches) + window_store",
-                                       alg_bytes, dev_ms, nwarp)
-        out["roofline"]["note"] = "launch-latency bound at 512^2 (6.6 MB per warp): the host loop is sequential over key frames like the reference"
+        out["roofline"] = hbm_roofline("warp_window_key_kernel (occlusion test + fixed-point remap of up to 4 neighbours + window mean; one launch per key frame, 16 per pass)",
+                                       alg_bytes, dev_ms, F_)
+        out["roofline"]["note"] = ("58 warps in 16 launches (round 3: 58 + 32 launches); 26 MB per launch: still latency- / gather-bound at 512^2, and "
+                                   "sequential over key frames like the reference (Gauss-Seidel)")
     else:
         # traffic model per frame: |aff| = Nsrc x 4096 fp32, 1 write (affinity GEMM) + 2 reads (top-k scan, threshold + sum: the survivors
         # leave as compact lists, the normalised matrix is never written back); Nsrc grows 4096 -> ~13.7k as the queue fills
@@ -585,7 +595,7 @@ def main():
 
     if rank == 0:
         if not a.no_cpu_baseline and world == 1 and emu is None and a.model == "sd15":
-            out["cpu_baseline"] = cpu_baseline(F_total, unet, full=a.full_cpu, single_branch=inv)
+            out["cpu_baseline"] = cpu_baseline(F_total, unet, full=a.full_cpu, single_branch=inv, quick=a.quick_cpu)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -113,9 +113,10 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
 /* tuning switches of a handle (not part of the reference's surface; tests use them for A/B runs).
  *   "ln_fold" (default 1, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
  *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU).
- *   "chain_bands" (default 0 = auto, env UNIVST_CHAIN_BANDS): the row-local chain behind a transformer block's self-attention
+ *   "chain_bands" (default 1 = off, env UNIVST_CHAIN_BANDS): the row-local chain behind a transformer block's self-attention
  *             (to_out -> attn2 -> to_out -> GEGLU feed-forward, attention.py:316-329) runs band by band over whole frames so that a band's
- *             intermediates stay in the 256 MB Infinity Cache: auto = bands of >= 65 536 rows, 1 = off, n = n bands.  Bit-identical. */
+ *             intermediates stay in the 256 MB Infinity Cache: 0 = auto (bands of >= 65 536 rows), n = n bands.  Bit-identical.  An
+ *             experiment kept as a switch: -13 % on the isolated chain (tools/bench_mall_bands.py), +0.4 ms per step in the graph. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
@@ -279,9 +280,11 @@ int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* 
                            int W, float threshold, void* stream);
 /* The whole window mean of ONE key frame in one launch (stable_diffusion.py:731-747, the inner loop over bias = -r .. r): frames
  * uint8 [F,H,W,3] is the Gauss-Seidel working copy, frame `key` is replaced in place by trunc(mean of {itself, get_warp(key, key+b)});
- * flows fp32 [nn][2][H][W][2] = (forward key -> key+b, backward key+b -> key) of the nn in-clip neighbours in increasing b.
- * Same arithmetic as univst_warp_accumulate + univst_accumulate_u8 + univst_window_store (bit-identical), 1 launch instead of 2r + 2. */
-int univst_warp_window_key(uint8_t* frames, const float* flows, int F, int H, int W, int key, int r, float threshold, void* stream);
+ * flows: HOST array of 2*nn device pointers, fp32 [H,W,2] each — (forward key -> key+b, backward key+b -> key) of the nn in-clip
+ * neighbours in increasing b (r <= 4).  Same arithmetic as univst_warp_accumulate + univst_accumulate_u8 + univst_window_store
+ * (bit-identical), 1 launch instead of 2r + 2. */
+int univst_warp_window_key(uint8_t* frames, const float* const* flows, int nn, int F, int H, int W, int key, int r, float threshold,
+                           void* stream);
 /* latent-space sliding window (no reference code exists for it — definition in csrc/warp.hip and DESIGN.md):
  * x0 [C,F,h,w] fp16 in place, lflow [F, 2r+1, h, w, 2] fp32 = flow from frame k to frame k+b in latent-pixel units. */
 int univst_latent_window_smooth(void* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, void* stream);

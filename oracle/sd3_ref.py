@@ -44,6 +44,9 @@ def latent_adain(cnt: torch.Tensor, sty: torch.Tensor) -> torch.Tensor:
     return ((cnt - mu) / torch.sqrt(var + 1e-5) * sty_std + sty_mean).to(cnt.dtype)
 
 
+SDPA_MAX_BATCH = None          # tests at config-5 size set this (frames per scaled_dot_product_attention call)
+
+
 def cross_frame_gather(x: torch.Tensor, clip_length: int = 16) -> torch.Tensor:
     """pnp_utils.py:53-78: x [(b f), heads, N, d] -> [(b f), heads, 3N, d], the tokens of frames ['first', f-1 (clipped), f] of the
     same clip concatenated along the token axis."""
@@ -95,7 +98,11 @@ def joint_attention(P: Dict[str, torch.Tensor], heads: int, hidden: torch.Tensor
         eq = _rms(eq, P.get("norm_added_q.weight"), rms_eps)
         ek = _rms(ek, P.get("norm_added_k.weight"), rms_eps)
         q, k, v = torch.cat([q, eq], dim=2), torch.cat([k, ek], dim=2), torch.cat([v, ev], dim=2)
-    o = F.scaled_dot_product_attention(q, k, v)
+    if SDPA_MAX_BATCH and B > SDPA_MAX_BATCH:              # (memory only: the fp32 math path materialises [B, heads, Nq, Nkv] scores)
+        o = torch.cat([F.scaled_dot_product_attention(q[i:i + SDPA_MAX_BATCH], k[i:i + SDPA_MAX_BATCH], v[i:i + SDPA_MAX_BATCH])
+                       for i in range(0, B, SDPA_MAX_BATCH)])
+    else:
+        o = F.scaled_dot_product_attention(q, k, v)
     o = o.transpose(1, 2).reshape(B, -1, heads * d)
     n_img = hidden.shape[1]
     if enc is not None:

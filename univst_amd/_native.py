@@ -94,7 +94,7 @@ SIGNATURES = {
     "univst_maskprop_frame": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "univst_maskprop_finalize": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "univst_warp_accumulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
-    "univst_warp_window_key": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "univst_warp_window_key": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "univst_latent_window_smooth": (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "univst_accumulate_u8": (_I, [_P, _P, _L, _P]),
     "univst_window_store": (_I, [_P, _F, _P, _L, _P]),

@@ -43,17 +43,19 @@ class CrossFrameProcessor:
     ``fused_gated_residual`` (addition, keyword only): the native MM-DiT block hands its gated residual to processors that
     advertise ``supports_fused_gated_residual``; the result is then hidden + gate * attention output (one epilogue, no extra pass)."""
     supports_fused_gated_residual = True
+    clip_length = 16        # pnp_utils.py:26 hard-codes 16 frames per clip inside __call__; an attribute here so that other clip lengths can be set
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, fused_gated_residual=None, **kwargs):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the UniVST path")
-        return _run(attn, hidden_states, encoder_hidden_states, False, idx, 0.0, 0.0, fuse=fused_gated_residual)
+        return _run(attn, hidden_states, encoder_hidden_states, False, idx, 0.0, 0.0, clip_length=self.clip_length, fuse=fused_gated_residual)
 
 
 class AttentionShiftProcessor:
     """pnp_utils.py:134-271: the same with the AdaIN-guided shift of the stylised branch inside eta1*50 <= idx <= eta2*50."""
 
     supports_fused_gated_residual = True
+    clip_length = 16        # pnp_utils.py:147 (same hard-coded 16)
 
     def __init__(self, eta1, eta2):
         self.eta1, self.eta2 = eta1, eta2
@@ -62,7 +64,7 @@ class AttentionShiftProcessor:
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, idx=-1, *args, fused_gated_residual=None, **kwargs):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is not used on the UniVST path")
-        return _run(attn, hidden_states, encoder_hidden_states, True, idx, self.eta1, self.thresh2, fuse=fused_gated_residual)
+        return _run(attn, hidden_states, encoder_hidden_states, True, idx, self.eta1, self.thresh2, clip_length=self.clip_length, fuse=fused_gated_residual)
 
 
 def register_spatial_attention_pnp(model, eta1=0.0, eta2=0.6):

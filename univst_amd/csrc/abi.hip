@@ -266,9 +266,9 @@ int univst_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* 
     UV_REQUIRE(key && now && fwd && bwd && acc, "warp_accumulate: null argument");
     return uv_launch_warp_accumulate(key, now, fwd, bwd, acc, Hh, W, thr, S(s));
 }
-int univst_warp_window_key(uint8_t* frames, const float* flows, int F, int Hh, int W, int key, int r, float thr, void* s) {
+int univst_warp_window_key(uint8_t* frames, const float* const* flows, int nn, int F, int Hh, int W, int key, int r, float thr, void* s) {
     UV_REQUIRE(frames, "warp_window_key: null argument");
-    return uv_launch_warp_window_key(frames, flows, F, Hh, W, key, r, thr, S(s));
+    return uv_launch_warp_window_key(frames, flows, nn, F, Hh, W, key, r, thr, S(s));
 }
 int univst_latent_window_smooth(void* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, void* s) {
     UV_REQUIRE(x0 && lflow, "latent_window_smooth: null argument");

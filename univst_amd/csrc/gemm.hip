@@ -367,6 +367,73 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
 }
 
 
+// GEGLU epilogue of the 256 x 320 tile, round 4.  The register epilogue above stores 8 bytes per lane: one store instruction covers 16
+// rows x 32 bytes, so the 80 KB a tile writes reach L2 as 2 560 partial-line requests — an in-kernel ablation (stores predicated off:
+// fixed cost per tile 14.0 -> 7.6 us at K = 320; GELU math off: -3.8 us) showed those stores, not the GELU, are the larger half of
+// the epilogue.  Here the math stays in the MFMA register layout (all 64 lanes busy, two values per packed instruction), the fp16
+// products go through a private 64 x 80 LDS slab per wave (row stride 176 B), and every store instruction writes 16 bytes per lane
+// over whole 160-byte row segments: 10 store instructions per wave instead of 20, full 128-byte lines.
+constexpr int GEGLU_SLD = 88;       // halfs per slab row (80 + 8 pad: 16-byte aligned rows)
+template <int MJ, int LNF>
+__device__ __forceinline__ void gemm_epilogue_geglu_slab(const GemmParams& p, const f4 (&acc)[10][MJ], half_t* slab, int mw, int nb, int lane,
+                                                         const float* cf, int cn, int rw) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const half_t* hb = reinterpret_cast<const half_t*>(cf + EPC_HALFS) + cn;
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        float2 ln = float2{0.f, 1.f};
+        if (LNF == 2) ln = reinterpret_cast<const float2*>(cf + EPC_ROWST)[rw + j * 16 + l15];
+#pragma unroll
+        for (int i = 0; i < 10; i += 2) {
+            float xv[4], gv[4];
+            if (LNF == 2) {
+                const float* cc = cf + cn + i * 16 + g * 4;
+                const f4 wx = *reinterpret_cast<const f4*>(cc), wg = *reinterpret_cast<const f4*>(cc + 16);
+                const f4 cx = *reinterpret_cast<const f4*>(cc + EPC_LNB), cg = *reinterpret_cast<const f4*>(cc + EPC_LNB + 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xv[r] = fmaf(ln.y, fmaf(-ln.x, wx[r], acc[i][j][r]), cx[r]);
+                    gv[r] = fmaf(ln.y, fmaf(-ln.x, wg[r], acc[i + 1][j][r]), cg[r]);
+                }
+            } else {
+                h4 bx = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
+                if (p.bias) {
+                    bx = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4);
+                    bg = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4 + 16);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xv[r] = acc[i][j][r] + (float)bx[r];
+                    gv[r] = acc[i + 1][j][r] + (float)bg[r];
+                }
+            }
+            h4 o;
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f2 y = geglu_erf2(f2{xv[r], xv[r + 1]}, f2{gv[r], gv[r + 1]});
+                o[r] = (half_t)y.x;
+                o[r + 1] = (half_t)y.y;
+            }
+            *reinterpret_cast<h4*>(&slab[(j * 16 + l15) * GEGLU_SLD + (i / 2) * 16 + g * 4]) = o;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int NCH = MJ * 16 * 10;              // 16-byte chunks of this wave's 16*MJ rows x 80 columns
+#pragma unroll
+    for (int it = 0; it < (NCH + 63) / 64; ++it) {
+        const int id = it * 64 + lane;
+        if (id >= NCH) continue;
+        const int row = id / 10, c = id - row * 10;
+        const int m = mw + row, n = nb / 2 + c * 8;
+        const h8 v = *reinterpret_cast<const h8*>(&slab[row * GEGLU_SLD + c * 8]);
+        // (measured and left out: nontemporal stores here are -5 % on the stand-alone K = 320 projection and 0 in the step — the
+        // feed-forward's second linear then misses what the plain stores leave in L2 / the Infinity Cache)
+        if (m < p.M && n < p.N / 2) *reinterpret_cast<h8*>(p.Y + (long)m * p.ldy + n) = v;
+    }
+}
+
 constexpr int BM_DEFAULT = 128;
 
 // Block tile BM x BN, 256 threads = 4 waves as 2(n) x 2(m); each wave NF x MF MFMA fragments.
@@ -770,6 +837,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
         }
         return;
     }
+    if (p.epi_lds == 3) {                 // GEGLU: math in registers, fp16 products through a per-wave LDS slab, 16-byte row-contiguous stores
+        if constexpr (MODE == 0 && (LNF == 0 || LNF == 2)) {
+            __syncthreads();              // every wave is done with the operand tiles
+            gemm_epilogue_geglu_slab<MJ, LNF>(p, acc, smem + wave * (64 * GEGLU_SLD), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160, wm * 16 * MJ);
+        }
+        return;
+    }
     if (p.epi_lds) {
         __syncthreads();                  // every wave is done with the operand tiles: smem becomes the transpose scratch
         gemm_epilogue_lds<MJ, LNF>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160,
@@ -1129,6 +1203,9 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             q.issue_mode = issue_mode;
             q.epi_lds = epi && (!p.geglu || epi == 2) && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && al16(p.bias2) && al16(p.rowbias) && p.ldrb % 8 == 0 &&
                         (!p.R || (p.ldr % 8 == 0 && al16(p.R)));
+            // GEGLU (round 4): register math + fp16 slab + row-contiguous 16-byte stores (epi_lds = 3); UNIVST_GEMM_EPI=4 keeps the 8-byte register stores (A/B)
+            const bool geglu_slab = p.geglu && mode == 0 && epi != 0 && epi != 2 && epi != 4 && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && p.N % 16 == 0;
+            if (geglu_slab) q.epi_lds = 3;
             // (Measured and rejected on this tile, DESIGN.md §4: a 32-wide-k 4-stage DMA ring with counted vmcnt (-10 %), the same
             // with two wave groups staggered by half a k tile + s_setprio (-0..18 %), and a five-phase / two-barriers-per-phase
             // schedule with in-place restaging two k tiles ahead (the guide's 8-phase template on this shape: -3 % linears,
@@ -1163,7 +1240,7 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                 return UV_OK;
             }
             if (lnf) {                // LayerNorm folded into this linear / row statistics emitted for the next one
-                if (p.geglu) q.epi_lds = 0;
+                if (p.geglu && !geglu_slab) q.epi_lds = 0;
                 UV_REQUIRE(mode == 0 && q.splits == 1 && (q.epi_lds || !p.stats_out) && (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0)) &&
                            (!p.stats_out || (!p.geglu && p.N % 160 == 0)), "linear: LayerNorm fold on a problem the direct 256x320 path does not take");
                 UV_REQUIRE(!(p.ln_stats && p.stats_out), "linear: a LayerNorm-folded linear cannot also emit row statistics");

@@ -117,7 +117,7 @@ int uv_launch_maskprop_frame(const float* feat_tar, const float* feat_src, const
 int uv_launch_maskprop_finalize(const float* segs, uint8_t* out, int ncls, int h, int w, int H, int W, void* ws, hipStream_t s);
 int uv_launch_warp_accumulate(const uint8_t* key, const uint8_t* now, const float* fwd, const float* bwd, float* acc, int H, int W,
                               float thr, hipStream_t s);
-int uv_launch_warp_window_key(uint8_t* est, const float* flows, int F, int H, int W, int key, int r, float thr, hipStream_t s);
+int uv_launch_warp_window_key(uint8_t* est, const float* const* flows, int nn, int F, int H, int W, int key, int r, float thr, hipStream_t s);
 int uv_launch_latent_window_smooth(half_t* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, hipStream_t s);
 int uv_launch_accumulate_u8(const uint8_t* f, float* acc, long n, hipStream_t s);
 int uv_launch_window_store(const float* acc, float weight, uint8_t* dst, long n, hipStream_t s);

@@ -871,6 +871,8 @@ struct Fwd {
         // round of 256-row tiles on the 256 CUs) the band's intermediates (42 MB each, hidden 168 MB) are re-read by the next kernel of
         // the chain while they are still in the 256 MB Infinity Cache instead of streaming from HBM, and the hidden buffer is
         // band-sized (tools/bench_mall_bands.py: -13 % on the four FF linears; bit-identical results: every kernel is row-local).
+        // OFF by default: inside the step (same box, alternating runs) the banded graph is 0.4 ms SLOWER (linears 16.7 -> 17.0 ms: three
+        // one-round launches per kernel lose more to launch tails than the cache returns).  Kept as a switch (chain_bands).
         const long N_rows = N;
         int nbands = 1;
         if (u.chain_bands != 1) {

@@ -57,9 +57,11 @@ __global__ __launch_bounds__(256) void warp_accumulate_kernel(const uint8_t* __r
 // warped exactly as warp_accumulate_kernel does, the terms are added in the reference's order b = -r .. r (sums of <= 9 integers
 // <= 255 are exact in fp32 whatever the order), the mean is stored with the same float -> uint8 truncation.  A thread reads the key
 // frame only at its own pixel and gathers from OTHER frames, so writing est[key] in place is race-free.
-// flows: [nn][2][H][W][2] — (forward key -> now, backward now -> key) of the nn in-clip neighbours in increasing bias.
-__global__ __launch_bounds__(256) void warp_window_key_kernel(uint8_t* __restrict__ est, const float* __restrict__ flows, int F, int H, int W, int key,
-                                                              int r, float thr) {
+// fl.p[2 s], fl.p[2 s + 1]: forward (key -> now) and backward (now -> key) flow [H][W][2] of the s-th in-clip neighbour, increasing bias.
+struct WindowFlows {
+    const float* p[16];
+};
+__global__ __launch_bounds__(256) void warp_window_key_kernel(uint8_t* __restrict__ est, WindowFlows fl, int F, int H, int W, int key, int r, float thr) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     const long HW = (long)H * W;
     if (p >= HW) return;
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void warp_window_key_kernel(uint8_t* __restric
             a0 += (float)k0; a1 += (float)k1; a2 += (float)k2;
             continue;
         }
-        const float* fwd = flows + (long)slot * 2 * HW * 2;
-        const float* bwd = fwd + HW * 2;
+        const float* fwd = fl.p[2 * slot];
+        const float* bwd = fl.p[2 * slot + 1];
         ++slot;
         const uint8_t* now = est + (long)nowi * HW * 3;
         const float fx = fwd[p * 2], fy = fwd[p * 2 + 1];
@@ -200,10 +202,17 @@ int uv_launch_warp_accumulate(const uint8_t* key, const uint8_t* now, const floa
     UV_LAUNCH_CHECK();
     return UV_OK;
 }
-int uv_launch_warp_window_key(uint8_t* est, const float* flows, int F, int H, int W, int key, int r, float thr, hipStream_t s) {
-    UV_REQUIRE(est && F >= 1 && key >= 0 && key < F && r >= 1 && r <= 8 && H >= 1 && W >= 1, "warp_window_key: bad geometry (F=%d key=%d r=%d)", F, key, r);
-    UV_REQUIRE(flows || F == 1, "warp_window_key: flows missing");
-    hipLaunchKernelGGL(warp_window_key_kernel, dim3((unsigned)(((long)H * W + 255) / 256)), dim3(256), 0, s, est, flows, F, H, W, key, r, thr);
+int uv_launch_warp_window_key(uint8_t* est, const float* const* flows, int nn, int F, int H, int W, int key, int r, float thr, hipStream_t s) {
+    UV_REQUIRE(est && F >= 1 && key >= 0 && key < F && r >= 1 && r <= 4 && H >= 1 && W >= 1, "warp_window_key: bad geometry (F=%d key=%d r=%d)", F, key, r);
+    int want = 0;
+    for (int b = -r; b <= r; ++b) want += (b != 0 && key + b >= 0 && key + b < F);
+    UV_REQUIRE(nn == want && (nn == 0 || flows), "warp_window_key: key frame %d of %d has %d in-clip neighbours within r = %d, %d flow pairs given", key, F, want, r, nn);
+    WindowFlows fl{};
+    for (int i = 0; i < 2 * nn; ++i) {
+        UV_REQUIRE(flows[i], "warp_window_key: flow pointer %d is null", i);
+        fl.p[i] = flows[i];
+    }
+    hipLaunchKernelGGL(warp_window_key_kernel, dim3((unsigned)(((long)H * W + 255) / 256)), dim3(256), 0, s, est, fl, F, H, W, key, r, thr);
     UV_LAUNCH_CHECK();
     return UV_OK;
 }

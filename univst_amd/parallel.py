@@ -199,7 +199,7 @@ class FrameShard:
                 return
             unet._sync_native()
             unet._frame_shard = None
-            _native.check(_native.load().univst_unet_set_comm(unet._native_handle, 0, 1, None, 0, None, None, None), "unet_set_comm(detach)")
+            _native.check(_native.load().univst_unet_set_comm(unet._native_handle, 0, 1, None, 0, _native.ALLREDUCE_FN(), _native.KVEXCHANGE_FN(), None), "unet_set_comm(detach)")
             try:
                 yield
             finally:

@@ -5,6 +5,8 @@ RAFT (torchvision ``raft_large`` + weights) is third-party and is NOT re-impleme
 ``flow_fn(img1_u8[H,W,3], img2_u8[H,W,3]) -> float32 [H,W,2]`` callable (device tensors).
 ``make_raft_flow_fn`` builds one from torchvision when it is installed (model created ONCE, not once per
 call as the reference does, cal_optica_flow.py:53-55)."""
+import ctypes as C
+
 import torch
 
 from .. import _native
@@ -90,13 +92,12 @@ def sliding_window_smooth(frames, flow_fn, mask01=None, r=2):
         # the flows of this key frame against its in-clip neighbours (RAFT stand-in; estimated on the CURRENT working copy like the
         # reference: frames k-2, k-1 are already smoothed), then ONE launch: warp every neighbour, add the key frame, store the mean
         nbrs = [key + bias for bias in range(-r, r + 1) if bias != 0 and 0 <= key + bias < F_]
-        flows = None
-        if nbrs:
-            key_frame = est[key]
-            flows = torch.stack([torch.stack([flow_fn(key_frame, est[n]).to(torch.float32), flow_fn(est[n], key_frame).to(torch.float32)])
-                                 for n in nbrs]).contiguous()
-        _native.check(lib.univst_warp_window_key(est.data_ptr(), None if flows is None else flows.data_ptr(), F_, H, W, key, r, 1.5,
-                                                 _native.stream_ptr()), "warp_window_key")
+        key_frame = est[key]
+        flows = []
+        for n in nbrs:
+            flows += [flow_fn(key_frame, est[n]).to(torch.float32).contiguous(), flow_fn(est[n], key_frame).to(torch.float32).contiguous()]
+        ptrs = (C.c_void_p * max(1, len(flows)))(*[f.data_ptr() for f in flows])
+        _native.check(lib.univst_warp_window_key(est.data_ptr(), ptrs, len(nbrs), F_, H, W, key, r, 1.5, _native.stream_ptr()), "warp_window_key")
     if mask01 is not None:
         m = mask01.to(torch.bool)[..., None]
         est = torch.where(m, ori, est)
