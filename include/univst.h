@@ -113,6 +113,9 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
 /* tuning switches of a handle (not part of the reference's surface; tests use them for A/B runs).
  *   "ln_fold" (default 1, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
  *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU).
+ *   "gn_producer" (default 1, env UNIVST_GN_PRODUCER): GroupNorm statistics (resnet.py:338,369, attention.py:121) are taken from the epilogue
+ *             of the conv / linear that writes the tensor instead of a separate pass over it, wherever that kernel is the 256x320 tile
+ *             (0: always the stand-alone pass; results differ by fp32 summation order only).
  *   "chain_bands" (default 1 = off, env UNIVST_CHAIN_BANDS): the row-local chain behind a transformer block's self-attention
  *             (to_out -> attn2 -> to_out -> GEGLU feed-forward, attention.py:316-329) runs band by band over whole frames so that a band's
  *             intermediates stay in the 256 MB Infinity Cache: 0 = auto (bands of >= 65 536 rows), n = n bands.  Bit-identical.  An

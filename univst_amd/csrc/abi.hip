@@ -46,6 +46,7 @@ int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     UV_REQUIRE(h, "unet_create: out of host memory");
     h->impl.cfg = *cfg;
     if (const char* e = getenv("UNIVST_LN_FOLD")) h->impl.ln_fold = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
+    if (const char* e = getenv("UNIVST_GN_PRODUCER")) h->impl.gn_producer = atoi(e) != 0;
     if (const char* e = getenv("UNIVST_CHAIN_BANDS")) h->impl.chain_bands = atoi(e) < 0 ? 0 : atoi(e);
     *out = h;
     return UV_OK;
@@ -55,6 +56,10 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value) {
     if (!strcmp(name, "ln_fold")) {
         UV_REQUIRE(value >= 0 && value <= 2, "unet_set_option: ln_fold is 0, 1 or 2");
         h->impl.ln_fold = value;
+        return UV_OK;
+    }
+    if (!strcmp(name, "gn_producer")) {
+        h->impl.gn_producer = value != 0;
         return UV_OK;
     }
     if (!strcmp(name, "chain_bands")) {

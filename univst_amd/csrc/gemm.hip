@@ -213,6 +213,17 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
 // transposes its 64 x 160 fp32 sub-tile 16 rows at a time through a private LDS slab (row stride 164 floats: conflict-free
 // ds_write_b128) and reads it back row-major, so residual loads and output stores are 16 B per lane over 320 contiguous bytes.
 // Arithmetic order is that of gemm_epilogue_row (fp32: acc + bias + rowbias + residual, one rounding, then bias2).
+typedef __fp16 fh2 __attribute__((ext_vector_type(2)));
+// sum over the 16 lanes of a DPP row in a fixed order (row_shr 1, 2, 4, 8 with zeros shifted in); the total lands in lane 15 of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#define UV_ROW_SHR_ADD(n) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + (n), 0xf, 0xf, true))
+    UV_ROW_SHR_ADD(1);
+    UV_ROW_SHR_ADD(2);
+    UV_ROW_SHR_ADD(4);
+    UV_ROW_SHR_ADD(8);
+#undef UV_ROW_SHR_ADD
+    return v;
+}
 constexpr int EPI_LDW = 164;
 // LDS map of the row-statistics producer (bytes; the operand buffers are dead by then): the eight transpose slabs end at
 // 8 * 16 * 164 * 4 = 83968; per-wave scratch from 90112 (8 x 2560 B).  The 192-row tile has 128 KB of LDS, the 256-row one 144 KB.
@@ -220,7 +231,8 @@ constexpr int EPI_STAT_SCRATCH = 90112;
 // cf: the block's LDS constants, cn = nb - n0, rw = first tile row of this wave; scratch: this wave's statistics scratch (LNF).
 template <int MJ, int LNF = 0>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 (&acc)[10][MJ], float* slab, int mw, int nb, int lane,
-                                                  const float* cf, int cn, int rw = 0, float2* scratch = nullptr) {
+                                                  const float* cf, int cn, int rw = 0, float2* scratch = nullptr, half_t* hs = nullptr) {
+    // hs: this wave's 16 x 160 fp16 scratch (5 KB) for the GroupNorm statistics of the stored tile (p.gn_out), else unused
     const int l15 = lane & 15, g = lane >> 4;
     const half_t* hb = reinterpret_cast<const half_t*>(cf + EPC_HALFS) + cn;
 #pragma unroll
@@ -299,6 +311,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     for (int r = 0; r < 8; ++r) o[r] = (half_t)v[r];
                 }
                 *reinterpret_cast<h8*>(p.Y + (long)m * p.ldy + n) = o;
+                if (LNF != 1 && p.gn_out) *reinterpret_cast<h8*>(&hs[row * 160 + c]) = o;       // the stored values, row-major, for the group statistics below
                 if (LNF == 1) {           // (sum, sum of squares) of the 8 values AS STORED: what the consuming GEMM will read
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -329,6 +342,41 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                 s2 += __shfl_xor(s2, 2, 64);
                 const int m = mrow0 + row;
                 if (q == 0 && m < p.M) *reinterpret_cast<float2*>(p.stats_out + ((long)m * (p.N / 160) + nb / 160) * 2) = float2{s1, s2};
+            }
+            if (LNF != 1 && p.gn_out) {
+                // GroupNorm statistics of this 16-row x 160-column piece AS STORED (round 4): lane (r = lane & 15, q = lane >> 4) takes row r,
+                // columns 40 q .. 40 q + 39 = 4, 2 or 1 whole channel groups (10, 20, 40 channels per group); sum and sum of squares by
+                // v_dot2_f32_f16 (exact fp16 products, fp32 accumulation; two values per instruction, no conversions), then a fixed-order
+                // DPP row reduction over the 16 rows.  Lane r = 15 of each q writes (sum, sumsq) of its groups for fragment mrow0 / 16.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const fh2 one2 = {(__fp16)1.f, (__fp16)1.f};
+                union { fh2 h[20]; h8 v[5]; } u;
+#pragma unroll
+                for (int e = 0; e < 5; ++e) u.v[e] = *reinterpret_cast<const h8*>(&hs[l15 * 160 + g * 40 + e * 8]);
+                float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+                const int hp = p.gn_gw >> 1;                       // pairs per group: 5, 10 or 20
+#pragma unroll
+                for (int k = 0; k < 20; ++k) {
+                    const int gi = hp == 5 ? k / 5 : (hp == 10 ? k / 10 : 0);
+                    a1[gi] = __builtin_amdgcn_fdot2(u.h[k], one2, a1[gi], false);
+                    a2[gi] = __builtin_amdgcn_fdot2(u.h[k], u.h[k], a2[gi], false);
+                }
+                const int ngpl = 20 / hp;
+#pragma unroll
+                for (int gi = 0; gi < 4; ++gi) {
+                    if (gi < ngpl) {
+                        a1[gi] = row16_sum(a1[gi]);
+                        a2[gi] = row16_sum(a2[gi]);
+                    }
+                }
+                if (l15 == 15 && mrow0 < p.M) {
+                    float2* dst = reinterpret_cast<float2*>(p.gn_out) + (long)(mrow0 >> 4) * p.gn_G + nb / p.gn_gw + g * ngpl;
+#pragma unroll
+                    for (int gi = 0; gi < 4; ++gi)
+                        if (gi < ngpl) dst[gi] = float2{a1[gi], a2[gi]};
+                }
             }
         } else {
             // interleaved [16 x | 16 gate] channel blocks -> 80 output columns per row: 16 rows x 10 chunks of 8
@@ -847,7 +895,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     if (p.epi_lds) {
         __syncthreads();                  // every wave is done with the operand tiles: smem becomes the transpose scratch
         gemm_epilogue_lds<MJ, LNF>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160,
-                                   wm * 16 * MJ, reinterpret_cast<float2*>(reinterpret_cast<char*>(smem) + EPI_STAT_SCRATCH) + wave * 320);
+                                   wm * 16 * MJ, reinterpret_cast<float2*>(reinterpret_cast<char*>(smem) + EPI_STAT_SCRATCH) + wave * 320,
+                                   reinterpret_cast<half_t*>(reinterpret_cast<char*>(smem) + EPI_STAT_SCRATCH) + wave * 2560);
         return;
     }
 #pragma unroll
@@ -1026,7 +1075,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     }
     if (p.epi_lds) {
         __syncthreads();
-        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160);
+        gemm_epilogue_lds<MJ>(p, acc, reinterpret_cast<float*>(smem) + wave * (16 * EPI_LDW), m0 + wm * 16 * MJ, n0 + wn * 160, lane, epc, wn * 160, 0, nullptr,
+                              reinterpret_cast<half_t*>(reinterpret_cast<char*>(smem) + EPI_STAT_SCRATCH) + wave * 2560);
         return;
     }
 #pragma unroll
@@ -1222,6 +1272,12 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                     UV_HIP(hipMallocAsync((void**)&q.partial, need, stream));
                     own_ws = true;
                 }
+            }
+            if (p.gn_out) {       // GroupNorm statistics from this epilogue: LDS epilogue, whole 160-column halves of 10 / 20 / 40-channel groups, no split-K
+                const bool ok = q.epi_lds == 1 && q.splits == 1 && !p.geglu && !p.stats_out && !p.act && !p.gate && p.N % 320 == 0 && p.M % 16 == 0 &&
+                                p.gn_G > 0 && p.gn_gw * p.gn_G == p.N && (p.gn_gw == 10 || p.gn_gw == 20 || p.gn_gw == 40);
+                if (!ok) q.gn_out = nullptr;
+                else if (p.gn_emitted) *p.gn_emitted = 1;
             }
             const dim3 bgrid((unsigned)(nblk * q.splits));
             if (use_patch) {

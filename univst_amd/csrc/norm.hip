@@ -264,7 +264,7 @@ int uv_groupnorm_workspace_floats(int S, int G) { return S * (GN_MAX_CHUNKS + 1)
 
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G,
                         float eps, const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part,
-                        hipStream_t stream, const UvGnComm* comm) {
+                        hipStream_t stream, const UvGnComm* comm, const float* pre_part) {
     const int C = C1 + C2;
     UV_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channels must be multiples of 8 (C1=%d C2=%d)", C1, C2);
     UV_REQUIRE(C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
@@ -286,9 +286,16 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
     size_t lds1 = (size_t)3 * TR * C * sizeof(float);
     UV_REQUIRE(lds1 <= 160 * 1024, "groupnorm: LDS %zu too large", lds1);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, S), dim3(block), lds1, stream, s1, s2, C1, C2, rows_per_stat, rpc,
-                       G, part);
-    UV_LAUNCH_CHECK();
+    const float* chunk_part = part;
+    if (pre_part) {               // the producing conv / linear left (sum, sumsq) per 16-row fragment and group: one chunk per fragment
+        UV_REQUIRE(!s2 && rows_per_stat % 16 == 0, "groupnorm: producer statistics need a single source and 16-row fragments");
+        nchunk = rows_per_stat / 16;
+        chunk_part = pre_part;
+    } else {
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, S), dim3(block), lds1, stream, s1, s2, C1, C2, rows_per_stat, rpc,
+                           G, part);
+        UV_LAUNCH_CHECK();
+    }
     int rpa = (int)(((long)rows_per_stat * S) / ((long)TR * 1024));       // rows per thread-row of the apply pass: 16 on big tensors
     rpa = rpa < 2 ? 2 : (rpa > 16 ? 16 : rpa);
     int nblk = (rows_per_stat + TR * rpa - 1) / (TR * rpa);
@@ -299,10 +306,10 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     long count_rows = rows_per_stat;
     // reduce the chunk partials ONCE ([S,nchunk,G,2] -> [S,G,2], stored right behind them) instead of letting each of
     // the ~2000 apply blocks walk all chunks serially (that prologue was ~1/2 of the apply kernel's time)
-    float* red = part + (size_t)S * nchunk * G * 2;
+    float* red = part + (size_t)S * (pre_part ? 0 : nchunk) * G * 2;
     const int SG2 = S * G * 2;
     if (comm && comm->world > 1) red = comm->red;
-    hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 3) / 4), dim3(256), 0, stream, part, red, nchunk, SG2, G * 2);
+    hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 3) / 4), dim3(256), 0, stream, chunk_part, red, nchunk, SG2, G * 2);
     UV_LAUNCH_CHECK();
     if (comm && comm->world > 1) {     // frame shard: sum the partials over ranks (SURVEY §8e coupling 1)
         int rc = comm->allreduce(comm->user, comm->byte_off, SG2);

@@ -30,6 +30,7 @@ struct WTensor {
 struct Act {   // NHWC activation: [imgs, H, W, C] fp16
     half_t* p = nullptr;
     int imgs = 0, H = 0, W = 0, C = 0;
+    const float* gst = nullptr;      // GroupNorm (sum, sumsq) per 16-row fragment and group, left by the producing conv / linear's epilogue ([rows/16][G][2]) or null
     long rows() const { return (long)imgs * H * W; }
 };
 
@@ -54,6 +55,7 @@ struct UNet {
     long temb_total = 0;
     Arena arena;
     bool finalized = false;
+    int gn_producer = 1;      // GroupNorm statistics from the producing conv / linear's epilogue where the tile geometry allows (UNIVST_GN_PRODUCER=0: always the stand-alone pass)
     int chain_bands = 1;      // post-attention chain of a transformer block in row bands: 1 off (default: measured +0.4 ms per step in the graph), 0 auto (bands of >= 65536 rows), n > 1 forced (UNIVST_CHAIN_BANDS)
     int ln_fold = 1;          // transformer-block LayerNorms folded into the neighbouring linears: 0 none, 1 norm1 + norm2, 2 also norm3 (UNIVST_LN_FOLD)
     unsigned* d_counter = nullptr;

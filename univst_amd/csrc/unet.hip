@@ -614,6 +614,22 @@ struct Fwd {
     float* sk_ws = nullptr;        // split-K fp32 partials (UV_SPLITK_WS_BYTES)
     half_t* temb_all = nullptr;    // [B, temb_total]: every resnet's time_emb_proj(SiLU(emb)), one launch per forward
     float* ad_ws = nullptr;
+    float* gst_pool = nullptr;     // bump region for the producers' GroupNorm statistics (never reused inside a forward)
+    size_t gst_left = 0;           // floats
+
+    float* gst_take(long rows) {   // [rows/16][G][2] floats, or null (pool exhausted / switched off: the consumer runs its own pass)
+        const size_t n = (size_t)(rows / 16) * u.cfg.norm_num_groups * 2;
+        if (!u.gn_producer || !gst_pool || rows % 16 != 0 || n > gst_left) return nullptr;
+        float* p = gst_pool;
+        gst_pool += n;
+        gst_left -= n;
+        return p;
+    }
+    void gst_give_back(long rows) {
+        const size_t n = (size_t)(rows / 16) * u.cfg.norm_num_groups * 2;
+        gst_pool -= n;
+        gst_left += n;
+    }
 
     half_t* alloc(long elems) {
         half_t* p = (half_t*)u.arena.alloc((size_t)elems * sizeof(half_t));
@@ -635,10 +651,12 @@ struct Fwd {
             gc.user = u.comm_user;
         }
         return uv_launch_groupnorm(a.p, b ? b->p : nullptr, a.C, b ? b->C : 0, a.rows(), rows_per_stat, u.cfg.norm_num_groups,
-                                   eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s, sharded ? &gc : nullptr);
+                                   eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s, sharded ? &gc : nullptr,
+                                   (!b && rows_per_stat % 16 == 0) ? a.gst : nullptr);
     }
+    // want_gst: let the epilogue leave the GroupNorm statistics of the output (Act::gst) for a following GroupNorm
     int conv(const Act& a, const Act* b, const std::string& p, int Cout, int taps, int stride, int up, const half_t* rowbias,
-             const half_t* R, Act* out, long ldrb = 0) {
+             const half_t* R, Act* out, long ldrb = 0, bool want_gst = false) {
         GemmParams g;
         g.X = a.p;
         g.X2 = b ? b->p : nullptr;
@@ -675,7 +693,22 @@ struct Fwd {
         if (!g.W || !g.bias) return u.missing_error();
         g.partial = sk_ws;
         g.partial_bytes = UV_SPLITK_WS_BYTES;
-        if (taps != 9 || !u.temporal_conv_active.count(p)) return uv_launch_gemm(g, 1, s);
+        out->gst = nullptr;
+        if (taps != 9 || !u.temporal_conv_active.count(p)) {
+            int emitted = 0;
+            const int G = u.cfg.norm_num_groups;
+            if (want_gst && Cout % G == 0 && (g.gn_out = gst_take(out->rows()))) {
+                g.gn_G = G;
+                g.gn_gw = Cout / G;
+                g.gn_emitted = &emitted;
+            }
+            RUN(uv_launch_gemm(g, 1, s));
+            if (g.gn_out) {
+                if (emitted) out->gst = g.gn_out;
+                else gst_give_back(out->rows());
+            }
+            return UV_OK;
+        }
         // TRAINED temporal conv (resnet.py:70-80): spatial conv (+ its bias) -> Conv1d over the frames of every pixel -> whatever the
         // caller wanted fused behind the PseudoConv3d (time-embedding row bias, residual).  The Conv1d runs as a 3x3 conv on the
         // geometry (image rows = frames, image columns = pixels) with zero side taps (embed_temporal_weight_kernel).
@@ -725,8 +758,18 @@ struct Fwd {
     // ln_slots = K / 160 slots per row) into this linear: `wkey` then names the derived "#ln" weight and the bias comes with it.
     int linear(const half_t* X, long ldx, long M, int K, const std::string& wkey, const std::string& bkey, int N, half_t* Y,
                long ldy, const half_t* R = nullptr, long ldr = 0, const half_t* bias2 = nullptr, int geglu = 0, float* stats_out = nullptr,
-               const float* ln_in = nullptr) {
+               const float* ln_in = nullptr, const float** gst_out = nullptr) {
         GemmParams g;
+        int emitted = 0;
+        if (gst_out) {
+            *gst_out = nullptr;
+            const int G = u.cfg.norm_num_groups;
+            if (N % G == 0 && (g.gn_out = gst_take(M))) {
+                g.gn_G = G;
+                g.gn_gw = N / G;
+                g.gn_emitted = &emitted;
+            }
+        }
         g.stats_out = stats_out;
         if (ln_in) {
             g.ln_stats = ln_in;
@@ -752,7 +795,12 @@ struct Fwd {
         if (!g.W || (!bkey.empty() && !ln_in && !g.bias)) return u.missing_error();
         g.partial = sk_ws;
         g.partial_bytes = UV_SPLITK_WS_BYTES;
-        return uv_launch_gemm(g, 0, s);
+        RUN(uv_launch_gemm(g, 0, s));
+        if (g.gn_out) {
+            if (emitted) *gst_out = g.gn_out;
+            else gst_give_back(M);
+        }
+        return UV_OK;
     }
 
     // frame shard (SURVEY §8e coupling 2): every frame attends to {prev, (cur), first}; the previous frame of this
@@ -791,7 +839,7 @@ struct Fwd {
         auto to = u.temb_off.find(p);
         UV_REQUIRE(to != u.temb_off.end() && temb_all, "%s: time_emb_proj missing", p.c_str());
         Act n1a{n1, x.imgs, x.H, x.W, Cin}, h;
-        RUN(conv(n1a, nullptr, p + ".conv1", Cout, 9, 1, 0, temb_all + to->second, nullptr, &h, u.temb_total));
+        RUN(conv(n1a, nullptr, p + ".conv1", Cout, 9, 1, 0, temb_all + to->second, nullptr, &h, u.temb_total, true));
         free(n1);
         half_t* n2 = alloc(h.rows() * Cout);
         if (!n2) return UV_ERR_STATE;
@@ -806,7 +854,7 @@ struct Fwd {
             UV_REQUIRE(!skip && x.C == Cout, "%s: no conv_shortcut but channel mismatch", p.c_str());
         }
         Act n2a{n2, x.imgs, x.H, x.W, Cout};
-        RUN(conv(n2a, nullptr, p + ".conv2", Cout, 9, 1, 0, nullptr, res, out));
+        RUN(conv(n2a, nullptr, p + ".conv2", Cout, 9, 1, 0, nullptr, res, out, 0, true));
         free(n2);
         if (sc.p) free(sc.p);
         return UV_OK;
@@ -973,7 +1021,7 @@ struct Fwd {
         out->p = alloc(rows * C);
         if (!out->p) return UV_ERR_STATE;
         RUN(linear(h4, C, rows, C, p + (u.find(p + ".proj_out.weight#nhwc") ? ".proj_out.weight#nhwc" : ".proj_out.weight"), p + ".proj_out.bias", C, out->p,
-                   C, x.p, C));
+                   C, x.p, C, nullptr, 0, nullptr, nullptr, &out->gst));
         free(h4);
         return UV_OK;
     }
@@ -1014,6 +1062,11 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     f.ad_ws = (float*)arena.alloc((size_t)F * 2 * boc[3] * 2 * sizeof(float) + 1024);
     f.sk_ws = (float*)arena.alloc(UV_SPLITK_WS_BYTES);
     UV_REQUIRE(f.gn_ws && f.ad_ws && f.sk_ws, "forward: arena too small");
+    if (gn_producer) {             // statistics of up to 64 level-0-sized tensors: [rows/16][G][2] fp32 each (3 MB at 3 x 16 x 64 x 64)
+        f.gst_left = (size_t)(((long)B * F * H * Wd + 15) / 16) * cfg.norm_num_groups * 2 * 64;
+        f.gst_pool = (float*)arena.alloc(f.gst_left * sizeof(float));
+        if (!f.gst_pool) f.gst_left = 0;
+    }
 
     // ---- time embedding (unet_3d_condition.py:359-365)
     half_t* tsin = f.alloc((long)B * C0);
@@ -1040,7 +1093,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     if (!x0.p) return UV_ERR_STATE;
     RUN(uv_launch_ncfhw_to_nhwc(sample, x0.p, B, cfg.in_channels, F, H * Wd, CP, s));
     Act x;
-    RUN(f.conv(x0, nullptr, "conv_in", C0, 9, 1, 0, nullptr, nullptr, &x));
+    RUN(f.conv(x0, nullptr, "conv_in", C0, 9, 1, 0, nullptr, nullptr, &x, 0, true));
     f.free(x0.p);
 
     std::vector<Act> skips;
@@ -1066,7 +1119,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
         }
         if (i != 3) {
             Act y;
-            RUN(f.conv(x, nullptr, p + ".downsamplers.0.conv", boc[i], 9, 2, 0, nullptr, nullptr, &y));
+            RUN(f.conv(x, nullptr, p + ".downsamplers.0.conv", boc[i], 9, 2, 0, nullptr, nullptr, &y, 0, true));
             x = y;
             skips.push_back(x);
         }
