@@ -272,6 +272,26 @@ _SD3_KEYS = {"to_q": "to_q.weight", "to_q_bias": "to_q.bias", "to_k": "to_k.weig
              "to_out": "to_out.0.weight", "to_out_bias": "to_out.0.bias", "to_add_out": "to_add_out.weight", "to_add_out_bias": "to_add_out.bias"}
 
 
+class Sd3AttnParams(dict):
+    """the fp16 device tensors behind a univst_sd3_attn_weights struct, keyed by its field names.  q | k | v (and the added
+    q | k | v) weights and biases are kept as views of ONE [3C, Cin] / [3C] tensor each, so that the library runs one projection
+    per stream (csrc/sd3.hip checks that the three pointers are consecutive).  Build once per attention module and pass it in
+    place of the state dict (backbones/video_diffusion_sd3/pnp_utils.py caches it, keyed by the parameters' storage and version)."""
+
+    def __init__(self, state, device):
+        super().__init__()
+        t = {k: state[v].detach().to(device=device, dtype=torch.float16).contiguous() for k, v in _SD3_KEYS.items() if state.get(v) is not None}
+        for trio in (("to_q", "to_k", "to_v"), ("add_q", "add_k", "add_v")) if os.environ.get("UNIVST_SD3_FUSED_QKV", "1") != "0" else ():
+            for suf in ("", "_bias"):
+                names = [n + suf for n in trio]
+                if all(n in t for n in names) and len({tuple(t[n].shape) for n in names}) == 1:
+                    fused = torch.cat([t[n] for n in names]).contiguous()
+                    rows = t[names[0]].shape[0]
+                    for i, n in enumerate(names):
+                        t[n] = fused[i * rows:(i + 1) * rows]
+        self.update(t)
+
+
 def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False, idx=-1, eta1=0.0, eta2=0.6, rms_eps=1e-6, fuse=None, comm=None):
     """CrossFrameProcessor / AttentionShiftProcessor of the reference's SD3 plugin on the native kernels.  params: the state dict
     of diffusers' Attention module (to_q.weight, ..., to_add_out.bias; missing entries = absent).  hidden [B, N, Cin],
@@ -281,7 +301,7 @@ def sd3_joint_attention(params, hidden, enc, heads, clip_length=16, shift=False,
     comm (optional): pointer of a connected univst_comm — the batch is this rank's clip_length frames of every branch (frame shard)."""
     _f16(hidden)
     B, N, Cin = hidden.shape
-    keep = {k: params[v].to(device=hidden.device, dtype=torch.float16).contiguous() for k, v in _SD3_KEYS.items() if params.get(v) is not None}
+    keep = params if isinstance(params, Sd3AttnParams) else Sd3AttnParams(params, hidden.device)
     w = Sd3AttnWeights(**{k: (keep[k].data_ptr() if k in keep else None) for k in Sd3AttnWeights._NAMES})
     inner = keep["to_q"].shape[0]
     out_i = torch.empty_like(hidden)

@@ -14,8 +14,17 @@ from ... import _native
 
 
 def _params(attn):
-    """state dict of the attention module the processor was handed (to_q.weight, ..., to_add_out.bias)."""
-    return {k: v for k, v in attn.state_dict().items()}
+    """the attention module's parameters (to_q.weight, ..., to_add_out.bias) as the native call wants them: fp16 device tensors with the
+    q | k | v projections fused (``_native.Sd3AttnParams``), cached on the module and rebuilt when a parameter is re-allocated, edited in
+    place through the tensor (version counter) or re-registered."""
+    ps = list(attn.parameters())
+    key = tuple((p.data_ptr(), p._version) for p in ps)
+    cached = attn.__dict__.get("_uv_native_params")
+    if cached is None or cached[0] != key:
+        dev = ps[0].device if ps and ps[0].device.type == "cuda" else torch.device("cuda")
+        cached = (key, _native.Sd3AttnParams(attn.state_dict(), dev))
+        attn.__dict__["_uv_native_params"] = cached
+    return cached[1]
 
 
 def _run(attn, hidden_states, encoder_hidden_states, shift, idx, eta1, eta2, clip_length=16, fuse=None):

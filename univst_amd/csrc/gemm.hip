@@ -1295,6 +1295,10 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
                 UV_LAUNCH_CHECK();
                 return UV_OK;
             }
+            // (Round 4, measured and removed: a PERSISTENT form of this tile for the GEGLU projections — one block per CU walking its tiles, the next
+            // tile's first k tile DMA'd into the free buffer before the epilogue — 22.8 vs 22.6 us per K = 320 tile, -2.5 % at K >= 640
+            // (256 VGPRs + 8 spilled dwords): block relaunch and prologue latency are not what the 13 us of fixed cost are made of.  The
+            // kernel is kept as tools/probes/gemm_big_persist_kernel.inc for the record.)
             if (lnf) {                // LayerNorm folded into this linear / row statistics emitted for the next one
                 if (p.geglu && !geglu_slab) q.epi_lds = 0;
                 UV_REQUIRE(mode == 0 && q.splits == 1 && (q.epi_lds || !p.stats_out) && (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0)) &&
