@@ -268,7 +268,18 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
     from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
     from univst_amd.parallel import Sd3FrameShard
     F_all, hl = a.frames, a.latent
-    shard = Sd3FrameShard(rank, world, F_all)
+    emu = None
+    if a.emulate_rank and world == 1:
+        # one rank of a w-GPU job alone, no wire: its F/w frames of every branch as whole clips of that length — the same kernels and key
+        # counts ([first | previous | current] + text) as the sharded rank runs, minus the K | V pack copies and the exchange
+        er, ew = (int(v) for v in a.emulate_rank.split("/"))
+        # exact for rank 0 only: its 'first' and 'previous' frames are local.  A rank r > 0 reads both from halo blocks, so each of its frames
+        # has three DISTINCT key sources (rank 0 with two frames: one and two after merging duplicates) — that needs the communicator's inboxes
+        assert er == 0, "--workload sd3_transfer --emulate-rank: only rank 0 can be emulated without a communicator (ranks > 0 need the halo blocks)"
+        emu = (er, ew)
+        shard = Sd3FrameShard(0, 1, F_all // ew)
+    else:
+        shard = Sd3FrameShard(rank, world, F_all)
     F_ = shard.local
     torch.manual_seed(33)
     with torch.device(dev):
@@ -276,6 +287,9 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
     model = model.half().requires_grad_(False)
     pipe = CustomStableDiffusion3Pipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler())
     pnp_utils.register_spatial_attention_pnp(pipe)
+    if emu is not None:
+        for proc in model.attn_processors.values():
+            proc.clip_length = F_
     shard.attach(model, tokens=(hl // 2) ** 2)
     g = torch.Generator(device=dev).manual_seed(5 + rank)
     rn = lambda *sh: torch.randn(*sh, generator=g, device=dev, dtype=torch.float16)          # noqa: E731
@@ -326,9 +340,10 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": round(ms, 2), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic latents + prompt embeddings, random-init weights (2.2 B parameters)",
            "config": {"workload": f"sd35_medium_mmdit_three_branch_transfer_{F_}x{hl * 8}x{hl * 8}_50rf", "frames": F_, "tokens_per_frame": N,
-                      "text_tokens": T, "batch": 3 * F_, "parallelism": "single" if world == 1 else f"frames{world} (IPC communicator)",
+                      "text_tokens": T, "batch": 3 * F_, "parallelism": (f"rank {emu[0]} of {emu[1]} emulated (no wire): {F_all // emu[1]} frames per branch" if emu else
+                                                                          "single" if world == 1 else f"frames{world} (IPC communicator)"),
                       "note": "BASELINE config 5 names 8 GPUs and fp8 QKV; fp16 here (the reference's --weight_dtype default); --gpus N shards the frames"}}
-    tf = fl / (ms * 1e-3) / 1e12 / world
+    tf = fl / (ms * 1e-3) / 1e12 / (emu[1] if emu else world)
     out["roofline"] = {"bound": "mfma", "kernel": "whole step (linears + joint attention), per GPU", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS,
                        "unit": "TFLOP/s", "frac": round(tf / PEAK_FP16_TFLOPS, 4), "traffic": None, "algorithmic_tflop_per_step": round(fl / 1e12, 2)}
     if not a.no_profile and world == 1:
