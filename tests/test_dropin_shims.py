@@ -74,6 +74,13 @@ def test_cli_scripts_keep_the_reference_flags(script):
                                              "--weight_dtype", "--time_steps", "--seed"]}[script]
     for flag in want:
         assert flag in out.stdout, f"{script}: flag {flag} missing from --help"
+    # round 4: the multi-GPU / smoother switches of the transfer scripts (additions; the reference's flags are untouched)
+    if script == "run_video_style_transfer_sd":
+        for flag in ("--smoother", "--content_path", "--no_shard", "--skip_dead_branches"):
+            assert flag in out.stdout, f"{script}: flag {flag} missing from --help"
+        assert "{none,pixel,latent}" in out.stdout
+    if script == "run_video_style_transfer_sd3":
+        assert "--no_shard" in out.stdout
 
 
 def test_mp4_content_input_goes_through_decord(monkeypatch, tmp_path):

@@ -6,6 +6,7 @@ G17 — plus the adaLN-modulate and per-head RMSNorm operators against the (pari
 JointTransformerBlock.  Tolerances: fp16 storage of q/k/v and of the projections: 4e-3 of the output scale (max), 1e-3 rms.
 Second half: the MM-DiT backbone mirror (models/transformer_3D_model.py) against the parity-unpinned restatement of diffusers'
 SD3Transformer2DModel."""
+import os
 import types
 
 import pytest
@@ -456,7 +457,30 @@ def test_sd3_end_to_end_chain_through_files(nat, tmp_path):
     assert zc.shape == (Fr, 16, 8, 8) and torch.isfinite(zc).all() and torch.isfinite(zs).all()
     assert len(list(out["c_inv"].glob("ddim_latents_*.pt"))) == 51 and len(list(out["s_inv"].glob("ddim_latents_*.pt"))) == 51
     ft = out["c_ft"] / "inversion_feature_map_1_block_5_step.pt"
-    assert torch.load(ft, weights_only=True).shape == (Fr, 4, 4, 128)
+    dumped = torch.load(ft, weights_only=True)
+    assert dumped.shape == (Fr, 4, 4, 128)
+    # rf_solver's MIDPOINT evaluation takes no ft_* arguments (flow_inversion.py:242-249), so the file holds the hidden state of the
+    # FIRST evaluation of step 5 — the transformer at (ddim_latents_5, t_curr) — not the midpoint's, which would overwrite it otherwise
+    import tempfile
+    z5 = load_ddim_latents_at_t(5, str(out["c_inv"])).cuda()
+    pipe.scheduler.set_timesteps(50, device="cuda")
+    sig = torch.flip(pipe.scheduler.sigmas, dims=[0])
+    t_curr, t_next = float(sig[5]), float(sig[6])
+    with tempfile.TemporaryDirectory() as td:
+        for tt, name in ((t_curr, "first"), (t_curr + (t_next - t_curr) / 2, "mid")):
+            zin = z5 if name == "first" else None
+            if name == "mid":
+                v = m(hidden_states=z5, timestep=torch.full((Fr,), 1000 * t_curr, device="cuda", dtype=torch.float16), encoder_hidden_states=pe,
+                      pooled_projections=pp, idx=5, return_dict=False)[0]
+                zin = (z5.float() + (t_next - t_curr) / 2 * v.float()).half()
+            m(hidden_states=zin, timestep=torch.full((Fr,), 1000 * tt, device="cuda", dtype=torch.float16), encoder_hidden_states=pe, pooled_projections=pp,
+              idx=5, ft_indices=[1], ft_timesteps=[5], ft_path=td, return_dict=False)
+            got = torch.load(os.path.join(td, "inversion_feature_map_1_block_5_step.pt"), weights_only=True)
+            d = (got.float() - dumped.float()).abs().max().item() / dumped.float().abs().max().item()
+            if name == "first":
+                assert d < 1e-3, ("the dumped feature is not the first evaluation's hidden state", d)
+            else:
+                assert d > 1e-2, ("the midpoint evaluation's features are indistinguishable: the check is vacuous", d)
     first = np.zeros((HW, HW), np.uint8)
     first[16:48, 8:40] = 1
     Image.fromarray(first).save(tmp_path / "first.png")

@@ -131,3 +131,52 @@ def test_sd3_frame_shard_slicing():
     assert Sd3FrameShard(0, 1, F_).gather_frames(t) is t
     with pytest.raises(ValueError):
         Sd3FrameShard(0, 3, 16)
+
+
+def test_init_distributed_without_a_launcher_is_a_no_op(monkeypatch):
+    """a plain `python run_video_style_transfer_sd.py` (no RANK / WORLD_SIZE): nothing is initialised, the pipeline stays on one GPU"""
+    import torch.distributed as dist
+    from univst_amd.parallel import init_distributed, dist_rank_world
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert init_distributed() == (0, 1)
+    assert not dist.is_initialized() and dist_rank_world() == (0, 1)
+
+
+def _init_rank(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    try:
+        import torch.distributed as dist
+        from univst_amd.parallel import init_distributed, dist_rank_world, FrameShard
+        got = init_distributed(backend="gloo", timeout_s=60)
+        again = init_distributed(backend="gloo")              # idempotent (the CLI and a caller may both do it)
+        sh = FrameShard(*dist_rank_world(), frames=8)
+        q.put((rank, got, again, dist_rank_world(), (sh.f0, sh.local), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:       # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, None, None, traceback.format_exc()))
+
+
+def test_init_distributed_from_the_launcher_environment_world2():
+    """what `torchrun --nproc-per-node 2 src/sd/run_video_style_transfer_sd.py` gives the script: RANK / WORLD_SIZE / LOCAL_RANK ->
+    a process group (gloo here: no GPU) and this rank's frame range"""
+    import socket
+    import torch.multiprocessing as mp
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_init_rank, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, got, again, rw, rng, err in res:
+        assert err is None, err
+        assert got == (rank, 2) and again == (rank, 2) and rw == (rank, 2) and rng == (rank * 4, 4)
