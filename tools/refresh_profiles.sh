@@ -5,7 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-3}
+ROUND=${ROUND:-4}
 O=$R/gpurun_out/profiles_new
 rm -rf $O && mkdir -p $O/raw
 cd $R
@@ -20,6 +20,19 @@ python bench.py --frames 32 --emulate-rank 0/8 --no-cpu-baseline > $O/round${ROU
 python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 7/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank7of8.json 2>> $O/raw/bench.err
 python bench.py --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8.json 2>> $O/raw/bench.err
+# is the per-rank step launch-bound?  kernel-time sum (rocprofv3) against the wall time of the same run: no gaps -> a hipGraph has nothing to remove
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats_emu -- python bench.py --emulate-rank 1/8 --steps 50 --warmup 2 --no-cpu-baseline --no-profile > $O/raw/emu_rocprof.json 2>> $O/raw/bench.err
+python - <<PY > $O/round${ROUND}_emulated_rank_kernel_sum.txt
+import csv, glob, json
+rows = list(csv.DictReader(open(glob.glob("$O/raw/stats_emu/*/*kernel_stats.csv")[0])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows) / 1e6
+calls = sum(int(r["Calls"]) for r in rows)
+b = json.loads(open("$O/raw/emu_rocprof.json").read().strip().splitlines()[-1])
+steps = b["steps"] + b["warmup"] + 1          # + the sharded latent_adain / set-up forward
+print(f"rank 1 of 8 emulated (F = 16, no wire), under rocprofv3: {b['ms_per_step']:.2f} ms per step by the wall clock; "
+      f"kernel-time sum {tot:.1f} ms over {calls} launches in ~{steps} steps = {tot / steps:.2f} ms and {calls / steps:.0f} launches per step")
+PY
+python bench.py --workload sd3_transfer --emulate-rank 0/8 --steps 5 --warmup 1 --no-profile > $O/round${ROUND}_bench_sd3_emulated_rank0of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --no-cpu-baseline --no-skip-dead-branches-leg > $O/round${ROUND}_bench_f32_n1.json 2>> $O/raw/bench.err
 python bench.py --model sd21 --no-cpu-baseline > $O/round${ROUND}_bench_sd21_n1.json 2>> $O/raw/bench.err
 [ "${FULLCPU:-1}" = 1 ] && python bench.py --full-cpu --no-profile --no-skip-dead-branches-leg > $O/round${ROUND}_bench_fullcpu.json 2>> $O/raw/bench.err
