@@ -45,5 +45,6 @@ python bench.py --gpus 8 --backend gloo --steps 4 --warmup 1 --no-cpu-baseline -
 tools/probes/coissue_probe > $O/round${ROUND}_coissue_probe.txt 2>&1
 tools/probes/ipc_probe 1 > $O/round${ROUND}_ipc_probe.txt 2>&1
 ROUND=$ROUND python tools/summarize_profiles.py $O
-rm -rf $O/raw/stats/*/*_agent_info.csv
+# gpurun merges at most 64 MiB back: the raw rocprofv3 traces (hundreds of MB of per-dispatch CSV) stay on the box, the summaries above are what is kept
+find $O/raw -type f -size +512k -delete
 ls -la $O
