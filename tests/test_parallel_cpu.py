@@ -180,3 +180,43 @@ def test_init_distributed_from_the_launcher_environment_world2():
     for rank, got, again, rw, rng, err in res:
         assert err is None, err
         assert got == (rank, 2) and again == (rank, 2) and rw == (rank, 2) and rng == (rank * 4, 4)
+
+
+def test_ipc_bringup_agrees_on_failure_before_any_device_collective():
+    """a rank whose univst_comm_create / hipIpcOpenMemHandle fails must not leave its peers spinning in the device-side
+    self-test.  On this GPU-less box univst_comm_create fails on every rank: each learns of the others' failure through the host-side
+    exchange (here two threads standing in for two processes) and ALL raise the same RuntimeError naming the failed ranks — the point
+    at which FrameShard.attach falls back to the torch.distributed callbacks on every rank together."""
+    import threading
+    from univst_amd import parallel
+    world = 2
+    bar = threading.Barrier(world)
+    box = [None] * world
+    out = {}
+
+    def exchange_for(rank):
+        def exchange(blob):
+            box[rank] = blob
+            bar.wait(timeout=60)
+            got = list(box)
+            bar.wait(timeout=60)
+            return got
+        return exchange
+
+    def run(rank):
+        try:
+            parallel.NativeIpcComm(rank, world, 1 << 20, device=torch.device("cpu"), exchange=exchange_for(rank))
+            out[rank] = "constructed"
+        except RuntimeError as e:
+            out[rank] = str(e)
+        except Exception as e:       # noqa: BLE001
+            out[rank] = f"{type(e).__name__}: {e}"
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert set(out) == {0, 1}, out
+    for r in range(world):
+        assert "IPC communicator: create/export failed on rank(s) [0, 1]" in out[r], out[r]
