@@ -571,6 +571,93 @@ def test_sd3_frame_shard_two_processes_ipc(nat, world):
             assert mx < 4e-3 and rms < 1e-3, (r, idx, mx, rms)
 
 
+def _sd3_pipeline_args(Fr=16, hw=8, seed=21):
+    """in-memory arguments of CustomStableDiffusion3Pipeline.video_style_transfer for the tiny MM-DiT: the 51 content / style inversion
+    latents, start latents, image latents, prompt embeddings, load_mask-style masks (uint8 {0,1} [1, F, 8 hw, 8 hw])"""
+    g = torch.Generator().manual_seed(seed)
+    ci = [torch.randn(Fr, 16, hw, hw, generator=g).half() for _ in range(51)]
+    sy = [torch.randn(Fr, 16, hw, hw, generator=g).half() * 0.8 + 0.1 for _ in range(51)]
+    start = torch.randn(Fr, 16, hw, hw, generator=g).half()
+    img = torch.randn(Fr, 16, hw, hw, generator=g).half()
+    pe, pp = torch.randn(1, 5, 64, generator=g).half(), torch.randn(1, 32, generator=g).half()
+    masks = torch.zeros(1, Fr, 8 * hw, 8 * hw, dtype=torch.uint8)
+    for f in range(Fr):
+        masks[0, f, 8 + f:40 + f, 16:48] = 1
+    return ci, sy, start, img, pe, pp, masks
+
+
+def _sd3_pipeline_call(pipe, args, **kw):
+    ci, sy, start, img, pe, pp, masks = args
+    return pipe.video_style_transfer("", latents=start.cuda(), img_latents=img.cuda(), num_inference_steps=50, content_inv_latents=ci, style_inv_latents=sy,
+                                     masks=masks, prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(), eta_base=0.85, eta_trend="constant", start_step=25,
+                                     end_step=39, output_type="latent", **kw).images
+
+
+def _sd3_pipeline_rank(rank, world, port, q):
+    """one process of `torchrun --nproc-per-node 2 src/sd3/run_video_style_transfer_sd3.py` from the pipeline on: launcher environment,
+    parallel.init_distributed, then the PIPELINE METHOD with the full clip as arguments on every rank"""
+    import os
+    import traceback
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      UNIVST_DIST_BACKEND="gloo")
+    try:
+        import torch.distributed as dist
+        from univst_amd.parallel import init_distributed, Sd3FrameShard
+        from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+        from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
+        from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
+        assert init_distributed() == (rank, world)
+        m, _ = _tiny_sd3(layers=2, dual=(0,))
+        pipe = CustomStableDiffusion3Pipeline(transformer=m, scheduler=FlowMatchEulerDiscreteScheduler())
+        pnp_utils.register_spatial_attention_pnp(pipe)
+        out = _sd3_pipeline_call(pipe, _sd3_pipeline_args())
+        assert isinstance(m.transformer_blocks[0].attn._uv_frame_shard, Sd3FrameShard)
+        torch.cuda.synchronize()
+        q.put((rank, out.float().cpu().numpy(), None))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_sd3_pipeline_method_frame_sharded_two_processes(nat):
+    """the SD3 twin of test_pipeline_method_frame_sharded_two_processes: two processes with the launcher's environment call
+    ``CustomStableDiffusion3Pipeline.video_style_transfer`` (tiny MM-DiT, 16 frames, 50 steps, masks, eta window) with the FULL clip;
+    the method shards the frames itself (Sd3FrameShard over the IPC communicator), every rank gets all frames back, and they equal the
+    unsharded call of this process."""
+    import socket
+    import torch.multiprocessing as mp
+    from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+    from univst_amd.backbones.video_diffusion_sd3.pipelines.custom_pipeline import CustomStableDiffusion3Pipeline
+    from univst_amd.schedulers import FlowMatchEulerDiscreteScheduler
+    world = 2
+    m, _ = _tiny_sd3(layers=2, dual=(0,))
+    pipe = CustomStableDiffusion3Pipeline(transformer=m, scheduler=FlowMatchEulerDiscreteScheduler())
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    want = _sd3_pipeline_call(pipe, _sd3_pipeline_args()).float().cpu()
+    assert torch.isfinite(want).all()
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_sd3_pipeline_rank, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = {}
+    for _ in range(world):
+        rank, out, err = q.get(timeout=900)
+        assert err is None, err
+        res[rank] = torch.from_numpy(out)
+    for pr in procs:
+        pr.join(timeout=120)
+    for r in range(world):
+        assert res[r].shape == want.shape
+        mx, rms = errs(res[r], want)
+        assert mx < 2e-2 and rms < 5e-3, (r, mx, rms)
+
+
 def test_bench_sd3_two_ranks_end_to_end():
     """`python bench.py --workload sd3_transfer --gpus 2`: bench.py spawns its two ranks, both share this box's GPU (gloo process group for
     the rendezvous), the frame-sharded MM-DiT step runs through the IPC communicator and rank 0 prints ONE JSON line with n_gpus = 2
