@@ -118,7 +118,8 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
  *             (0: always the stand-alone pass; results differ by fp32 summation order only).
  *   "chain_bands" (default 1 = off, env UNIVST_CHAIN_BANDS): the row-local chain behind a transformer block's self-attention
  *             (to_out -> attn2 -> to_out -> GEGLU feed-forward, attention.py:316-329) runs band by band over whole frames so that a band's
- *             intermediates stay in the 256 MB Infinity Cache: 0 = auto (bands of >= 65 536 rows), n = n bands.  Bit-identical.  An
+ *             intermediates stay in the 256 MB Infinity Cache: 0 = auto (bands of >= 65 536 rows), n = n bands.  Same results up to fp32
+ *             summation order (a band may take another tile than the full tensor).  An
  *             experiment kept as a switch: -13 % on the isolated chain (tools/bench_mall_bands.py), +0.4 ms per step in the graph. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 

@@ -918,7 +918,7 @@ struct Fwd {
         // an unsharded clip: 196 608 rows, every C-wide tensor 126 MB, the 4C-wide hidden one 503 MB): with bands of 65 536 rows (one
         // round of 256-row tiles on the 256 CUs) the band's intermediates (42 MB each, hidden 168 MB) are re-read by the next kernel of
         // the chain while they are still in the 256 MB Infinity Cache instead of streaming from HBM, and the hidden buffer is
-        // band-sized (tools/bench_mall_bands.py: -13 % on the four FF linears; bit-identical results: every kernel is row-local).
+        // band-sized (tools/bench_mall_bands.py: -13 % on the four FF linears; every kernel is row-local: same results up to fp32 summation order).
         // OFF by default: inside the step (same box, alternating runs) the banded graph is 0.4 ms SLOWER (linears 16.7 -> 17.0 ms: three
         // one-round launches per kernel lose more to launch tails than the cache returns).  Kept as a switch (chain_bands).
         const long N_rows = N;
@@ -928,6 +928,8 @@ struct Fwd {
             int want = u.chain_bands > 1 ? u.chain_bands : (int)(rows / target);
             while (want > 1 && (x.imgs % want != 0 || (u.chain_bands <= 1 && rows / want < target))) --want;
             nbands = want < 1 ? 1 : want;
+            // the folded LayerNorms need the direct 256x320 path for the band's row count as well: a level too small for that stays unbanded
+            if (nbands > 1 && fold && !(uv_linear_takes_big_direct(rows / nbands, C, C) && (!fold3 || uv_linear_takes_big_direct(rows / nbands, 8 * C, C)))) nbands = 1;
         }
         const int band_imgs = x.imgs / nbands;
         const long brows = (long)band_imgs * N_rows;
