@@ -9,6 +9,7 @@
 // Replaces: resnet.py:338,369 + unet_3d_condition.py:439 (5-D GroupNorm eps 1e-5 + SiLU),
 // attention.py:69-71,121 (per-frame GroupNorm eps 1e-6), attention.py:289-343 (LayerNorms).
 #include "common.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace {
@@ -167,6 +168,82 @@ __global__ void gn_apply_kernel(const half_t* __restrict__ s1, const half_t* __r
     }
 }
 
+// ONE-LAUNCH GroupNorm for SMALL tensors (round 4; the deep UNet levels and every level of a frame shard, where the three launches of the
+// streaming form above are 8 us of launch latency each for a few MB): one block per (stat unit, group).  Thread t walks rows t, t + 256, ...
+// of the unit and the group's cpg channels of each row (20 - 160 B: 4-byte loads), sums about its first value (pivot) in fp32, the block
+// merges the 256 (n, pivot, sum, sumsq) tuples about zero in double in a fixed order; then — MODE 0 — the same block normalises and
+// stores its rows x channels (second read out of L2), or — MODE 1, cross-rank statistics — writes (sum, sumsq) for the all-reduce and the
+// streaming apply kernel follows.  Two sources (virtual concat) are read per channel pair; C1 is even, so a pair never straddles them.
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict__ s1, const half_t* __restrict__ s2, int C1, int C2, int rows_per_stat,
+                                                       int G, float eps, const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int silu,
+                                                       half_t* __restrict__ out, float* __restrict__ red) {
+    const int C = C1 + C2, cpg = C / G, np = cpg >> 1;          // channel pairs per group
+    const int s = blockIdx.y, gi = blockIdx.x, tid = threadIdx.x;
+    const int c0 = gi * cpg;
+    const long rbase = (long)s * rows_per_stat;
+    __shared__ double sh[2][256];
+    __shared__ float st[2];
+    float pv = 0.f, s1f = 0.f, s2f = 0.f;
+    int n = 0;
+    bool have = false;
+    for (int r = tid; r < rows_per_stat; r += 256) {
+        for (int q = 0; q < np; ++q) {
+            const int c = c0 + 2 * q;
+            const h2 v = c < C1 ? *reinterpret_cast<const h2*>(s1 + (rbase + r) * C1 + c) : *reinterpret_cast<const h2*>(s2 + (rbase + r) * C2 + (c - C1));
+            if (!have) { pv = (float)v[0]; have = true; }
+            const float a = (float)v[0] - pv, b = (float)v[1] - pv;
+            s1f += a + b;
+            s2f = fmaf(a, a, fmaf(b, b, s2f));
+            n += 2;
+        }
+    }
+    const double dn = (double)n, dp = (double)pv;
+    sh[0][tid] = dn * dp + (double)s1f;
+    sh[1][tid] = (double)s2f + 2.0 * dp * (double)s1f + dn * dp * dp;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {          // fixed tree: deterministic
+        if (tid < off) {
+            sh[0][tid] += sh[0][tid + off];
+            sh[1][tid] += sh[1][tid + off];
+        }
+        __syncthreads();
+    }
+    if (MODE == 1) {
+        if (tid == 0) {
+            red[((long)s * G + gi) * 2] = (float)sh[0][0];
+            red[((long)s * G + gi) * 2 + 1] = (float)sh[1][0];
+        }
+        return;
+    }
+    if (tid == 0) {
+        const double cnt = (double)rows_per_stat * cpg;
+        const double mean = sh[0][0] / cnt;
+        double var = sh[1][0] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        st[0] = (float)mean;
+        st[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mu = st[0], rs = st[1];
+    for (int r = tid; r < rows_per_stat; r += 256) {
+        for (int q = 0; q < np; ++q) {
+            const int c = c0 + 2 * q;
+            const h2 v = c < C1 ? *reinterpret_cast<const h2*>(s1 + (rbase + r) * C1 + c) : *reinterpret_cast<const h2*>(s2 + (rbase + r) * C2 + (c - C1));
+            const h2 gv = *reinterpret_cast<const h2*>(gamma + c), bv = *reinterpret_cast<const h2*>(beta + c);
+            h2 o;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const float sc = rs * (float)gv[e];
+                float y = (float)v[e] * sc + ((float)bv[e] - mu * sc);
+                if (silu) y = silu_f(y);
+                o[e] = (half_t)y;
+            }
+            *reinterpret_cast<h2*>(out + (rbase + r) * C + c) = o;
+        }
+    }
+}
+
 // [S, nchunk, G, 2] -> [S, G, 2]: the 768-byte per-(branch, group) partial sums a frame shard all-reduces.
 // One wave per output value (fixed lane-strided order + shuffle tree -> deterministic); the serial
 // 128-load walk of a single thread per output cost 19 us per GroupNorm, a quarter of the whole operator.
@@ -271,6 +348,38 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     UV_REQUIRE(C / 8 <= 1024, "groupnorm: C=%d too large", C);
     UV_REQUIRE(rows % rows_per_stat == 0, "groupnorm: rows=%ld not a multiple of rows_per_stat=%d", rows, rows_per_stat);
     const int S = (int)(rows / rows_per_stat);
+    // small tensors: one launch (statistics + apply in the block that owns the (unit, group)), or statistics only when they are summed over ranks
+    static const long small_bytes = getenv("UNIVST_GN_SMALL") ? atol(getenv("UNIVST_GN_SMALL")) : (4L << 20);
+    const bool sharded_stats = comm && comm->world > 1;
+    if (!pre_part && (C / G) % 2 == 0 && C1 % 2 == 0 && rows * C * 2 <= small_bytes && (long)S * G >= 48) {
+        uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
+        if (!sharded_stats) {
+            hipLaunchKernelGGL((gn_small_kernel<0>), dim3(G, S), dim3(256), 0, stream, s1, s2, C1, C2, rows_per_stat, G, eps, gamma, beta, silu, out, (float*)nullptr);
+            uv_prof_end(stream);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+        hipLaunchKernelGGL((gn_small_kernel<1>), dim3(G, S), dim3(256), 0, stream, s1, s2, C1, C2, rows_per_stat, G, eps, gamma, beta, silu, out, comm->red);
+        UV_LAUNCH_CHECK();
+        int rc = comm->allreduce(comm->user, comm->byte_off, S * G * 2);
+        if (rc) {
+            uv_set_error("groupnorm: all-reduce callback failed (%d)", rc);
+            return UV_ERR_STATE;
+        }
+        int blk;
+        const int TRs = gn_geometry(C, &blk);
+        int rpa_ = (int)(((long)rows_per_stat * S) / ((long)TRs * 1024));
+        rpa_ = rpa_ < 2 ? 2 : (rpa_ > 16 ? 16 : rpa_);
+        int nb_ = (rows_per_stat + TRs * rpa_ - 1) / (TRs * rpa_);
+        if (nb_ < 1) nb_ = 1;
+        const int rpb_ = (rows_per_stat + nb_ - 1) / nb_;
+        nb_ = (rows_per_stat + rpb_ - 1) / rpb_;
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(nb_, S), dim3(blk), 2 * G * sizeof(float), stream, s1, s2, C1, C2, rows_per_stat, rpb_, G, 1, eps,
+                           (long)rows_per_stat * comm->world, comm->red, gamma, beta, silu, out);
+        uv_prof_end(stream);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
     int block;
     const int TR = gn_geometry(C, &block);
     // chunks: <= GN_MAX_CHUNKS per stat unit, 32 rows per thread-row on big tensors; on small ones (frame shards, single-branch calls,
