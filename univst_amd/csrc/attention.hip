@@ -1508,8 +1508,9 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     if constexpr (DPAD == 64 && DV16 == 4) {
         // head_dim 64 with prescaled q (the SD3 joint attention folds the factor into the q RMSNorm weight): software-pipelined kernel.
         // UNIVST_ATTN_PP64=0 (A/B aid): the generic body
-        static const int pp64 = getenv("UNIVST_ATTN_PP64") ? atoi(getenv("UNIVST_ATTN_PP64")) : 1;
-        // (pp64 = 2: also the text queries of a joint attention — 333 rows over 12 621 keys — which otherwise take the generic body)
+        static const int pp64 = getenv("UNIVST_ATTN_PP64") ? atoi(getenv("UNIVST_ATTN_PP64")) : 2;
+        // (pp64 = 2, default since round 4: also the text queries of a joint attention — 333 rows over 12 621 keys — which otherwise take the
+        // generic body: SD3.5 step 944 / 947 -> 934 / 943 ms, same box; 1 = image queries only)
         if (pp64 && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && p.kx && p.Nq >= 192))) {
             const int nqb4 = (p.Nq + 255) / 256;
             hipLaunchKernelGGL((attn_pp64_kernel<0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
