@@ -111,7 +111,7 @@ int univst_comm_status(univst_comm* c);
 int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
 
 /* tuning switches of a handle (not part of the reference's surface; tests use them for A/B runs).
- *   "ln_fold" (default 1, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
+ *   "ln_fold" (default 2 since round 4, env UNIVST_LN_FOLD): fold the transformer blocks' LayerNorms (attention.py:311,321,329) into the
  *             linears around them instead of launching them separately: 0 none, 1 norm1 + norm2, 2 also norm3 (-> GEGLU).
  *   "gn_producer" (default 1, env UNIVST_GN_PRODUCER): GroupNorm statistics (resnet.py:338,369, attention.py:121) are taken from the epilogue
  *             of the conv / linear that writes the tensor instead of a separate pass over it, wherever that kernel is the 256x320 tile
