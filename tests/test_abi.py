@@ -108,3 +108,22 @@ def test_pipeline_input_checks_match_the_reference():
     with pytest.raises(ValueError, match="list of generators of length 2"):
         pipe.prepare_latents(1, 4, 16, 512, 512, torch.float32, dev, [torch.Generator(), torch.Generator()])
     assert pipe.prepare_extra_step_kwargs(None, 0.0) == {"eta": 0.0, "generator": None}      # DDIMScheduler.step takes both (:402-410)
+
+
+def test_sd3_attention_parameters_are_kept_as_consecutive_views():
+    """_native.Sd3AttnParams: q | k | v (and the added q | k | v) weights / biases are views of ONE tensor each, so that csrc/sd3.hip sees
+    consecutive pointers and runs one projection per stream; shapes and values are those of the state dict."""
+    import torch
+    from univst_amd import _native
+    g = torch.Generator().manual_seed(3)
+    C, Cin = 16, 24
+    sd = {f"{n}.weight": torch.randn(C, Cin, generator=g) for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj")}
+    sd.update({f"{n}.bias": torch.randn(C, generator=g) for n in ("to_q", "to_k", "to_v")})
+    sd["to_out.0.weight"] = torch.randn(Cin, C, generator=g)
+    p = _native.Sd3AttnParams(sd, "cpu")
+    for trio, key in ((("to_q", "to_k", "to_v"), "{}"), (("add_q", "add_k", "add_v"), "{}"), (("to_q", "to_k", "to_v"), "{}_bias")):
+        a, b, c = (p[key.format(n)] for n in trio)
+        step = a.numel() * a.element_size()
+        assert b.data_ptr() - a.data_ptr() == step and c.data_ptr() - b.data_ptr() == step and a.dtype == torch.float16 and a.is_contiguous()
+    assert torch.equal(p["to_k"], sd["to_k.weight"].half()) and torch.equal(p["add_v"], sd["add_v_proj.weight"].half())
+    assert "add_q_bias" not in p and "to_out" in p and "norm_q" not in p
