@@ -108,10 +108,6 @@ __global__ __launch_bounds__(VARIANT == 0 ? 512 : 256, VARIANT == 0 ? 2 : 1) voi
         __syncthreads();
         W4_LOAD0(A0, B0)
         // kt = 0 (peeled: its first MFMAs take C = 0), the steady state without a branch, kt = nk - 1 (peeled: nothing left to prefetch)
-        auto half0 = [&](int kt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        (void)half0;
 #define W4_MID(KT)                                                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                     \
         __syncthreads();                                                                                       \

@@ -75,6 +75,7 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * -2.8853900817779268f));
 }
 
+// (superseded in the GEGLU epilogues by geglu_erf2 below, round 4; kept as the scalar form the packed one was checked against)
 __device__ __forceinline__ float gelu_erf_f(float x) {
     const float ax = fabsf(x);
     const float z = ax * 0.70710678118654752f;
