@@ -239,7 +239,9 @@ def run_aux_workload(a, dev):
         out["roofline"] = hbm_roofline("maskprop_frame (row-normalise, fp32-MFMA affinity GEMM + exp, top-15 threshold + survivor lists, sparse label product) + finalize",
                                        alg_bytes, dev_ms, F_ - 1)
         out["roofline"]["note"] = ("host randperm sub-sampling between frames (reference RNG stream; one scalar per frame comes back from the device) "
-                                   "is inside the timed region; the affinity GEMM (up to 72 GFLOP fp32 per frame on v_mfma_f32_32x32x2_f32) is the largest kernel")
+                                   "is inside the timed region; the affinity GEMM (up to 72 GFLOP fp32 per frame on v_mfma_f32_32x32x2_f32) is the largest kernel and is "
+                                   "COMPUTE-bound: rocprofv3 (round 4) 0.62 ms per frame on average = 116 TFLOP/s = 0.74 of the 157 TFLOP/s fp32 matrix peak, a third of the "
+                                   "clip's kernel time (top-k 26 %, sparse label product 23 %) - the HBM fraction above under-rates this line")
     return out
 
 
