@@ -92,6 +92,10 @@ __global__ __launch_bounds__(256) void comm_multicast_kernel(const uint4* __rest
         const uint4 v = src[i];
         for (int k = 0; k < dsts.n; ++k) dsts.d[k][i] = v;
     }
+    // (round 4, belt and braces for the first contact with a real multi-GPU node: every thread drains its payload stores and writes them back at
+    // SYSTEM scope before its wave ends — the publication no longer rests on the end-of-kernel release + the next kernel's fence alone; on one GPU
+    // the two are indistinguishable, and the cost is one fence per thread on a kernel that moves megabytes)
+    __threadfence_system();
 }
 struct Flags {
     unsigned* f[UV_COMM_MAXW + 1];
