@@ -372,10 +372,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     }
                 }
                 if (l15 == 15 && mrow0 < p.M) {
-                    float2* dst = reinterpret_cast<float2*>(p.gn_out) + (long)(mrow0 >> 4) * p.gn_G + nb / p.gn_gw + g * ngpl;
+                    // layout [sub-group][fragment]: the consumer's reduction walks the fragments of one sub-group — contiguous there
+                    float2* dst = reinterpret_cast<float2*>(p.gn_out) + (long)(nb / p.gn_gw + g * ngpl) * (p.M >> 4) + (mrow0 >> 4);
 #pragma unroll
                     for (int gi = 0; gi < 4; ++gi)
-                        if (gi < ngpl) dst[gi] = float2{a1[gi], a2[gi]};
+                        if (gi < ngpl) dst[(long)gi * (p.M >> 4)] = float2{a1[gi], a2[gi]};
                 }
             }
         } else {

@@ -44,9 +44,9 @@ struct GemmParams {
     //  consumer: X holds the RAW rows, W = gamma (.) W, and the epilogue computes rstd*(acc - mean*ln_wsum[n]) + ln_bias[n]
     //            with (mean, rstd) over K from ln_stats[m][ln_slots][2]  (ln_bias already contains the linear's own bias).
     // GroupNorm statistics from the producer's epilogue (round 4; 256x320 kernels with the LDS epilogue, no GEGLU / split-K): for every
-    // 16-row fragment m/16 and every channel group of gn_gw = C / gn_G channels (10, 20 or 40) the (sum, sum of squares) of the fp16
-    // values AS STORED go to gn_out[m/16][gn_G][2] — the `part` layout of uv_launch_groupnorm with one chunk per fragment, so the
-    // statistics pass over the tensor (a third of a GroupNorm's traffic) disappears.  *gn_emitted is set to 1 when the launch took a
+    // 16-row fragment m/16 and every SUB-GROUP of gn_gw = 10 channels (gn_G = N / 10 of them; 10 divides every group width of the UNet, also
+    // those of a channel concat) the (sum, sum of squares) of the fp16 values AS STORED go to gn_out[sub-group][m/16][2]; uv_launch_groupnorm
+    // sums fragments and sub-groups into its groups, so the statistics pass over the tensor (a third of a GroupNorm's traffic) disappears.  *gn_emitted is set to 1 when the launch took a
     // path that writes them (the caller falls back to the stand-alone pass otherwise).
     float* gn_out = nullptr;
     int gn_G = 0, gn_gw = 0;
@@ -96,10 +96,11 @@ struct UvGnComm {      // cross-rank reduction hook of the 5-D GroupNorm (frame 
     void* user = nullptr;
 };
 int uv_groupnorm_workspace_floats(int S, int G);
-// pre_part: statistics already emitted by the producer (GemmParams::gn_out, [rows/16][G][2]): the partial-sum pass is skipped
+// pre_part / pre_part2: statistics already emitted by the producers of s1 / s2 (GemmParams::gn_out, [C/10][rows/16][2] each: 10-channel
+// sub-groups): the partial-sum pass over the tensor(s) is skipped when every source has them
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G, float eps,
                         const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part, hipStream_t stream,
-                        const UvGnComm* comm = nullptr, const float* pre_part = nullptr);
+                        const UvGnComm* comm = nullptr, const float* pre_part = nullptr, const float* pre_part2 = nullptr);
 int uv_launch_layernorm(const half_t* x, long ldx, half_t* y, long ldy, const half_t* gamma, const half_t* beta, long rows,
                         int C, float eps, hipStream_t stream);
 int uv_launch_attention(const AttnParams& p, hipStream_t stream);

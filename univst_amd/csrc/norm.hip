@@ -260,6 +260,50 @@ __global__ __launch_bounds__(256) void gn_reduce_chunks_kernel(const float* __re
     if (lane == 0) red[i] = (float)a;
 }
 
+// Producer statistics (GemmParams::gn_out) -> [S, G, 2].  The producers leave (sum, sumsq) per 16-row fragment and per SUB-GROUP of 10 channels
+// ([C/10][rows/16][2] per source tensor, sub-group major: the reduction below reads contiguous runs): 10 divides every group width of the SD-v1.5 / v2.1 UNets (10, 20, 30, 40, 60, 80), so the groups of a
+// virtual channel concat (up-block resnets: 960 = 640 + 320 channels in groups of 30, ...) are whole runs of sub-groups of the two sources and the
+// statistics pass over the LARGEST tensors of the step goes as well.  Deterministic (fixed strides, fixed reduction tree).
+__global__ __launch_bounds__(256) void gn_reduce_sub_kernel(const float2* __restrict__ p1, const float2* __restrict__ p2, int SG1, int SG2, int nfrag,
+                                                            int spg, int G, int SG, float* __restrict__ red) {
+    // one BLOCK per (stat unit, group): 256 threads stride over the group's spg x nfrag partials (a single wave walking 4 096 .. 12 288 of them
+    // was latency-bound: 16 - 85 us per GroupNorm), four independent loads in flight per thread, block reduction in double in a fixed order
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const int s = i / G, gi = i - s * G;
+    const long F = (long)nfrag * (SG / G);                     // fragments of the whole tensor (all stat units)
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < spg; ++j) {
+        const int sg = gi * spg + j;
+        const float2* col = (sg < SG1 ? p1 + (long)sg * F : p2 + (long)(sg - SG1) * F) + (long)s * nfrag;       // [sub-group][fragment]: contiguous
+        int c = tid;
+        for (; c + 768 < nfrag; c += 1024) {
+            const float2 v0 = col[c], v1 = col[c + 256], v2 = col[c + 512], v3 = col[c + 768];
+            a += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            b += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+        }
+        for (; c < nfrag; c += 256) {
+            const float2 v = col[c];
+            a += (double)v.x;
+            b += (double)v.y;
+        }
+    }
+    __shared__ double sh[2][256];
+    sh[0][tid] = a;
+    sh[1][tid] = b;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            sh[0][tid] += sh[0][tid + off];
+            sh[1][tid] += sh[1][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        red[(long)i * 2] = (float)sh[0][0];
+        red[(long)i * 2 + 1] = (float)sh[1][0];
+    }
+}
+
 // LayerNorm over the last dim, one wave per row, row kept in registers (two-pass variance).
 template <int MAXCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx, half_t* __restrict__ y,
@@ -341,7 +385,7 @@ int uv_groupnorm_workspace_floats(int S, int G) { return S * (GN_MAX_CHUNKS + 1)
 
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G,
                         float eps, const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part,
-                        hipStream_t stream, const UvGnComm* comm, const float* pre_part) {
+                        hipStream_t stream, const UvGnComm* comm, const float* pre_part, const float* pre_part2) {
     const int C = C1 + C2;
     UV_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channels must be multiples of 8 (C1=%d C2=%d)", C1, C2);
     UV_REQUIRE(C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
@@ -351,6 +395,8 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     // small tensors: one launch (statistics + apply in the block that owns the (unit, group)), or statistics only when they are summed over ranks
     static const long small_bytes = getenv("UNIVST_GN_SMALL") ? atol(getenv("UNIVST_GN_SMALL")) : (4L << 20);
     const bool sharded_stats = comm && comm->world > 1;
+    // producer statistics are usable when every source has them and the groups are whole runs of 10-channel sub-groups
+    if (pre_part && !((!s2 || pre_part2) && (C / G) % 10 == 0 && C1 % 10 == 0 && C2 % 10 == 0 && rows_per_stat % 16 == 0)) pre_part = nullptr;
     if (!pre_part && (C / G) % 2 == 0 && C1 % 2 == 0 && rows * C * 2 <= small_bytes && (long)S * G >= 48) {
         uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
         if (!sharded_stats) {
@@ -396,11 +442,7 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     size_t lds1 = (size_t)3 * TR * C * sizeof(float);
     UV_REQUIRE(lds1 <= 160 * 1024, "groupnorm: LDS %zu too large", lds1);
     const float* chunk_part = part;
-    if (pre_part) {               // the producing conv / linear left (sum, sumsq) per 16-row fragment and group: one chunk per fragment
-        UV_REQUIRE(!s2 && rows_per_stat % 16 == 0, "groupnorm: producer statistics need a single source and 16-row fragments");
-        nchunk = rows_per_stat / 16;
-        chunk_part = pre_part;
-    } else {
+    if (!pre_part) {
         hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, S), dim3(block), lds1, stream, s1, s2, C1, C2, rows_per_stat, rpc,
                            G, part);
         UV_LAUNCH_CHECK();
@@ -418,7 +460,12 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     float* red = part + (size_t)S * (pre_part ? 0 : nchunk) * G * 2;
     const int SG2 = S * G * 2;
     if (comm && comm->world > 1) red = comm->red;
-    hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 3) / 4), dim3(256), 0, stream, chunk_part, red, nchunk, SG2, G * 2);
+    if (pre_part) {       // the producing convs / linears left (sum, sumsq) per 16-row fragment and 10-channel sub-group: no pass over the tensor(s)
+        hipLaunchKernelGGL(gn_reduce_sub_kernel, dim3(S * G), dim3(256), 0, stream, reinterpret_cast<const float2*>(pre_part),
+                           reinterpret_cast<const float2*>(pre_part2), C1 / 10, C2 / 10, rows_per_stat / 16, (C / G) / 10, G, S * G, red);
+    } else {
+        hipLaunchKernelGGL(gn_reduce_chunks_kernel, dim3((SG2 + 3) / 4), dim3(256), 0, stream, chunk_part, red, nchunk, SG2, G * 2);
+    }
     UV_LAUNCH_CHECK();
     if (comm && comm->world > 1) {     // frame shard: sum the partials over ranks (SURVEY §8e coupling 1)
         int rc = comm->allreduce(comm->user, comm->byte_off, SG2);

@@ -30,7 +30,7 @@ struct WTensor {
 struct Act {   // NHWC activation: [imgs, H, W, C] fp16
     half_t* p = nullptr;
     int imgs = 0, H = 0, W = 0, C = 0;
-    const float* gst = nullptr;      // GroupNorm (sum, sumsq) per 16-row fragment and group, left by the producing conv / linear's epilogue ([rows/16][G][2]) or null
+    const float* gst = nullptr;      // GroupNorm (sum, sumsq) per 16-row fragment and 10-channel sub-group, left by the producing conv / linear's epilogue ([C/10][rows/16][2]) or null
     long rows() const { return (long)imgs * H * W; }
 };
 

@@ -617,16 +617,16 @@ struct Fwd {
     float* gst_pool = nullptr;     // bump region for the producers' GroupNorm statistics (never reused inside a forward)
     size_t gst_left = 0;           // floats
 
-    float* gst_take(long rows) {   // [rows/16][G][2] floats, or null (pool exhausted / switched off: the consumer runs its own pass)
-        const size_t n = (size_t)(rows / 16) * u.cfg.norm_num_groups * 2;
-        if (!u.gn_producer || !gst_pool || rows % 16 != 0 || n > gst_left) return nullptr;
+    float* gst_take(long rows, int C) {   // [C/10][rows/16][2] floats, or null (pool exhausted / switched off: the consumer runs its own pass)
+        const size_t n = (size_t)(rows / 16) * (C / 10) * 2;
+        if (!u.gn_producer || !gst_pool || rows % 16 != 0 || C % 10 != 0 || n > gst_left) return nullptr;
         float* p = gst_pool;
         gst_pool += n;
         gst_left -= n;
         return p;
     }
-    void gst_give_back(long rows) {
-        const size_t n = (size_t)(rows / 16) * u.cfg.norm_num_groups * 2;
+    void gst_give_back(long rows, int C) {
+        const size_t n = (size_t)(rows / 16) * (C / 10) * 2;
         gst_pool -= n;
         gst_left += n;
     }
@@ -652,7 +652,7 @@ struct Fwd {
         }
         return uv_launch_groupnorm(a.p, b ? b->p : nullptr, a.C, b ? b->C : 0, a.rows(), rows_per_stat, u.cfg.norm_num_groups,
                                    eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s, sharded ? &gc : nullptr,
-                                   (!b && rows_per_stat % 16 == 0) ? a.gst : nullptr);
+                                   rows_per_stat % 16 == 0 ? a.gst : nullptr, b ? b->gst : nullptr);
     }
     // want_gst: let the epilogue leave the GroupNorm statistics of the output (Act::gst) for a following GroupNorm
     int conv(const Act& a, const Act* b, const std::string& p, int Cout, int taps, int stride, int up, const half_t* rowbias,
@@ -696,16 +696,15 @@ struct Fwd {
         out->gst = nullptr;
         if (taps != 9 || !u.temporal_conv_active.count(p)) {
             int emitted = 0;
-            const int G = u.cfg.norm_num_groups;
-            if (want_gst && Cout % G == 0 && (g.gn_out = gst_take(out->rows()))) {
-                g.gn_G = G;
-                g.gn_gw = Cout / G;
+            if (want_gst && (g.gn_out = gst_take(out->rows(), Cout))) {
+                g.gn_G = Cout / 10;           // sub-groups of 10 channels: every group width of the UNet (10 .. 80) is a multiple
+                g.gn_gw = 10;
                 g.gn_emitted = &emitted;
             }
             RUN(uv_launch_gemm(g, 1, s));
             if (g.gn_out) {
                 if (emitted) out->gst = g.gn_out;
-                else gst_give_back(out->rows());
+                else gst_give_back(out->rows(), Cout);
             }
             return UV_OK;
         }
@@ -763,10 +762,9 @@ struct Fwd {
         int emitted = 0;
         if (gst_out) {
             *gst_out = nullptr;
-            const int G = u.cfg.norm_num_groups;
-            if (N % G == 0 && (g.gn_out = gst_take(M))) {
-                g.gn_G = G;
-                g.gn_gw = N / G;
+            if ((g.gn_out = gst_take(M, N))) {
+                g.gn_G = N / 10;
+                g.gn_gw = 10;
                 g.gn_emitted = &emitted;
             }
         }
@@ -798,7 +796,7 @@ struct Fwd {
         RUN(uv_launch_gemm(g, 0, s));
         if (g.gn_out) {
             if (emitted) *gst_out = g.gn_out;
-            else gst_give_back(M);
+            else gst_give_back(M, N);
         }
         return UV_OK;
     }
@@ -1159,7 +1157,7 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
         }
         if (i != 3) {
             Act y;
-            RUN(f.conv(x, nullptr, p + ".upsamplers.0.conv", Cout, 9, 1, 1, nullptr, nullptr, &y));
+            RUN(f.conv(x, nullptr, p + ".upsamplers.0.conv", Cout, 9, 1, 1, nullptr, nullptr, &y, 0, true));
             f.free(x.p);
             x = y;
         }
