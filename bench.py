@@ -150,7 +150,12 @@ def cpu_baseline(frames_full, unet=None, full=False, single_branch=False, quick=
         extrap = not full
     else:
         a_in = step(x2, ctx, True)
-        ratio = 1.0 if single_branch else step(x2, ctx, False) / a_in
+        ratio = 1.0
+        if not single_branch:          # the two kinds of step twice each, best of each: a 6 s step on 16 threads is noisy (one draw gave 0.70)
+            a_out = step(x2, ctx, False)
+            a_in = min(a_in, step(x2, ctx, True))
+            a_out = min(a_out, step(x2, ctx, False))
+            ratio = a_out / a_in
         x, ctx = inputs(frames_full)
         t_in = step(x, ctx, True)
         t_out, scale = t_in * ratio, 1.0
