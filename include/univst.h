@@ -135,8 +135,9 @@ int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, c
 int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr, void* Y, int64_t ldy,
                         int M, int N, int K, int act, const void* gate, int64_t ld_gate, int rows_per_gate, void* stream);
 /* The same linear with a LayerNorm folded into it and / or row statistics emitted for the next one (what the UNet graph does with
- * norm1/2/3 of a transformer block, attention.py:311-329).  Only for problems the direct 256x320 tile takes (N % 320 == 0, at
- * least 150 tiles; else UNIVST_ERR_ARG).
+ * norm1/2/3 of a transformer block, attention.py:311-329).  For problems the direct 256x320 tile takes (N % 320 == 0, at least
+ * 150 tiles) and, without GEGLU, for problems the 128-wide tile runs without split-K (N % 160 == 0 for stats_out); else
+ * UNIVST_ERR_ARG — a split-K problem has its epilogue in the reduction kernel.
  *   stats_out (may be NULL): fp32 [M][N/160][2] <- (sum, sum of squares) of the stored fp16 outputs per 160-column slot.
  *   ln_stats  (may be NULL): fp32 [M][K/160][2] written by the linear that produced X.  Then X holds the RAW rows, W must be
  *             fp16(gamma[k] * W[n][k]), ln_wsum[n] = sum_k of that, ln_bias[n] = bias[n] + sum_k beta[k] W[n][k] (fp32), bias NULL,

@@ -79,15 +79,17 @@ def _enc(text):
     return Enc()
 
 
-def test_f16_forward_inside_and_outside_pnp_window(sd15):
+@pytest.mark.parametrize("F_", [16, 2])
+def test_f16_forward_inside_and_outside_pnp_window(sd15, F_):
     """one three-branch forward at F = 16 (48 frames x 4096 tokens: the big-tile GEMM / tap-inner conv / d=40 pipelined
     attention dispatches the headline bench runs, 16 distinct key-source frames) inside (idx 12) and outside (idx 40)
     the PnP window.  Tolerance: max err <= 5e-3 * max|ref|, relative RMS <= 3e-3 over 22 ResBlocks + 16 transformer
-    blocks of fp16 storage (measured on MI355X: 1.6e-3 / 1.6e-3; the F = 2 test keeps the looser round-1 bound)."""
+    blocks of fp16 storage (measured on MI355X: 1.6e-3 / 1.6e-3; the F = 2 test keeps the looser round-1 bound).
+    F = 2 is the problem size of ONE RANK of an 8-GPU job (6 frame-branches): the 128-wide kernels with the LayerNorm fold, split-K
+    at the deep levels, the one-launch GroupNorm — same bar."""
     from univst_amd.backbones.video_diffusion_sd import pnp_utils
     unet, sd = sd15
     cfg = unet_ref.SD15_CONFIG
-    F_ = 16
     g = torch.Generator().manual_seed(3)
     x = torch.randn(3, 4, F_, 64, 64, generator=g).half().cuda()
     ctx = torch.randn(1, 77, 768, generator=g).half().cuda().expand(3, -1, -1).contiguous()
@@ -103,7 +105,7 @@ def test_f16_forward_inside_and_outside_pnp_window(sd15):
         out[f"idx{idx}"] = dict(max_rel=mx, rms_rel=rms)
         assert torch.isfinite(got.float()).all()
         assert mx < 5e-3 and rms < 3e-3, (idx, mx, rms)
-    record("f16_forward", out)
+    record("f16_forward" if F_ == 16 else f"f{F_}_forward", out)
 
 
 @pytest.mark.parametrize("tag", ["mask", "nomask"])

@@ -566,7 +566,11 @@ def test_mask_resize(nat):
 
 @pytest.mark.parametrize("M,C,Nf,geglu,res,row_mean", [(49152, 320, 960, False, False, 0.7), (49152, 320, 320, False, True, 0.7),
                                                        (49152, 640, 5120, True, False, 0.7), (40000, 1280, 1280, False, False, 0.7),
-                                                       (49152, 320, 960, False, False, 30.0)])
+                                                       (49152, 320, 960, False, False, 30.0),
+                                                       # the levels of one rank of an 8-GPU frame shard: producer (and, but for the first, consumer) on the
+                                                       # 128-wide kernel — 160-, 128-column tiles of 128 rows and 128-column tiles of 64 rows; a ragged M
+                                                       (24576, 320, 960, False, False, 0.7), (24576, 320, 320, False, True, 0.7), (6144, 640, 640, False, True, 0.7),
+                                                       (6144, 640, 1920, False, False, 0.7), (6100, 640, 640, False, False, 30.0)])
 def test_linear_layernorm_fold(nat, M, C, Nf, geglu, res, row_mean):
     """univst_linear_ln: a producer linear leaves (sum, sumsq) per row and 160-column slot; the consumer runs on the raw rows with
     gamma folded into the weight and applies rstd * (acc - mean * wsum) + lnb.  Reference: torch fp32 LayerNorm -> linear
@@ -612,8 +616,13 @@ def test_linear_layernorm_fold(nat, M, C, Nf, geglu, res, row_mean):
     assert mx < 2e-3 and rms < 5e-4, (mx, rms)
 
 
-def test_linear_layernorm_fold_rejects_small_problems(nat):
-    x = torch.randn(1024, 320).half().cuda()
-    w = torch.randn(320, 320).half().cuda()
+def test_linear_layernorm_fold_rejects_split_k_problems(nat):
+    """a problem the launcher runs with split-K (few tiles, long reduction: the 16x16 level of a frame shard) has its epilogue in the
+    reduction kernel: no statistics, no fold — refused loudly instead of silently skipped"""
+    x = torch.randn(1536, 1280).half().cuda()
+    w = torch.randn(1280, 1280).half().cuda()
     with pytest.raises(RuntimeError, match="not taken by the direct"):
-        nat.linear_ln(x, w, stats_out=torch.empty(1024, 2, 2, device="cuda"))
+        nat.linear_ln(x, w, stats_out=torch.empty(1536, 8, 2, device="cuda"))
+    st = torch.zeros(1536, 8, 2, device="cuda")
+    with pytest.raises(RuntimeError, match="not taken by the direct"):
+        nat.linear_ln(x, w, ln=(st, torch.zeros(1280, device="cuda"), torch.zeros(1280, device="cuda")))

@@ -135,7 +135,8 @@ int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias
                      float* stats_out, void* s) {
     UV_REQUIRE(X && W && Y, "linear_ln: null argument");
     UV_REQUIRE(!ln_stats || (ln_wsum && ln_bias && K % 160 == 0 && !bias), "linear_ln: a folded LayerNorm needs wsum, lnb (which holds the bias) and K %% 160 == 0");
-    UV_REQUIRE(uv_linear_takes_big_direct(M, N, K), "linear_ln: M=%d N=%d K=%d is not taken by the direct 256x320 path (N %% 320 == 0 and >= 150 tiles)", M, N, K);
+    UV_REQUIRE((!stats_out || uv_linear_fold_producer_ok(M, N, K)) && (!ln_stats || uv_linear_fold_consumer_ok(M, N, K, geglu != 0)),
+               "linear_ln: M=%d N=%d K=%d is not taken by the direct 256x320 path (N %% 320 == 0 and >= 150 tiles) nor by the 128-wide path without split-K", M, N, K);
     GemmParams g;
     g.X = H(X); g.ldx = ldx; g.W = H(W); g.bias = H(bias); g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy;
     g.M = M; g.N = N; g.K = K; g.geglu = geglu;

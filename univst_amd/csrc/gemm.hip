@@ -73,9 +73,11 @@ __device__ __forceinline__ void epi_const_stage(const GemmParams& p, int m0, int
 // (fp16, made at finalize), wsum[n] = sum_k W'[n][k] and lnb[n] = bias[n] + sum_k beta[k] W[n][k]:
 //     LN(x) W^T + bias  =  rstd * (x W'^T  -  mean * wsum)  +  lnb
 // so the GEMM runs on the RAW rows x and (mean, rstd) of a row — `ln` — enter only here.
+// st (128-row kernels, LNF == 1): += (sum, sum of squares) of the values this lane stores — the row statistics a following folded
+// LayerNorm reads; the caller combines the lanes and waves that share the row.
 template <int NF, int LNF = 0, bool CL = false>       // CL: per-column constants from LDS (cf), else from memory
 __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 (&col)[NF], int m, int nb, int g, const float* cf = nullptr,
-                                                  int cn = 0, float2 ln = float2{0.f, 1.f}) {
+                                                  int cn = 0, float2 ln = float2{0.f, 1.f}, float2* st = nullptr) {
     if (m >= p.M) return;
     const half_t* rbias = p.rowbias ? p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) : nullptr;
     const half_t* hb = CL ? reinterpret_cast<const half_t*>(cf + EPC_HALFS) + cn : nullptr;
@@ -145,7 +147,14 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
         for (int r = 0; r < 4; ++r) v[r] = col[i][r];
         if (n + 3 < p.N) {
             if (LNF == 2) {
-                const f4 ws = *reinterpret_cast<const f4*>(cf + cn + i * 16 + g * 4), cb = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + i * 16 + g * 4);
+                f4 ws, cb;
+                if constexpr (CL) {
+                    ws = *reinterpret_cast<const f4*>(cf + cn + i * 16 + g * 4);
+                    cb = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + i * 16 + g * 4);
+                } else {
+                    ws = *reinterpret_cast<const f4*>(p.ln_wsum + n);
+                    cb = *reinterpret_cast<const f4*>(p.ln_bias + n);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(ln.y, fmaf(-ln.x, ws[r], v[r]), cb[r]);
             }
@@ -187,6 +196,16 @@ __device__ __forceinline__ void gemm_epilogue_row(const GemmParams& p, const f4 
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+            }
+            if constexpr (LNF == 1 && !CL) {
+                if (st) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = (float)o[r];
+                        st->x += t;
+                        st->y = fmaf(t, t, st->y);
+                    }
+                }
             }
             *reinterpret_cast<h4*>(p.Y + (long)m * p.ldy + n) = o;
         } else {
@@ -491,7 +510,10 @@ constexpr int BM_DEFAULT = 128;
 // chunk index is XOR-swizzled with (row & 7) — applied to the per-lane SOURCE address and to the fragment reads.  Two LDS
 // buffers, one barrier per 64-wide k tile; the next tile's DMA flies under this tile's MFMAs.  (Register-staged variants of
 // this kernel were measured earlier in the round: the ds_write pass + its second barrier cost half the time)
-template <int NF, int MODE, int MF = 4>
+// LNF (linears without split-K): 1 = leaves the row statistics of its output for a following folded LayerNorm (NF = 5 only: the
+// block's 160 columns are one slot of GemmParams::stats_out), 2 = folds the LayerNorm of its input into the epilogue (ln_stats; the
+// per-column constants come from memory) — what gemm_big_kernel does for the large levels, here for the levels of a frame shard.
+template <int NF, int MODE, int MF = 4, int LNF = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     constexpr int BK = 64, LDSH = 64;
     constexpr int BN = NF * 32;
@@ -612,6 +634,27 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int nk = kt1 - kt0;            // k tiles of THIS block (all of them unless split-K)
     issue_tile(kt0 * BK, 0);
     advance_k();
+    // LNF == 2: (mean, rstd) of the lane's rows from the producer's slots — requested here, under the first tile's DMA
+    float2 lnrow[LNF == 2 ? MF : 1];
+    if constexpr (LNF == 2) {
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int m = m0 + wm * 16 * MF + j * 16 + l15;
+            float s1 = 0.f, s2 = 0.f;
+            if (m < p.M) {
+                const float2* sp = reinterpret_cast<const float2*>(p.ln_stats) + (long)m * p.ln_slots;
+                for (int e = 0; e < p.ln_slots; ++e) {
+                    const float2 t = sp[e];
+                    s1 += t.x;
+                    s2 += t.y;
+                }
+            }
+            const float inv = 1.f / (float)p.K;
+            const float mean = s1 * inv;
+            const float var = fmaxf(fmaf(-mean, mean, s2 * inv), 0.f);
+            lnrow[j] = float2{mean, rsqrtf(var + p.ln_eps)};
+        }
+    }
     const int sw = l15 & 7;
     for (int kt = 0; kt < nk; ++kt) {
         const half_t* Xs = smem + (kt & 1) * TILE;
@@ -648,6 +691,50 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             for (int i = 0; i < NF; ++i) {
                 const int n = n0 + wn * NF * 16 + i * 16 + g * 4;
                 if (n + 3 < p.N) *reinterpret_cast<f4*>(row + n) = acc[i][j];
+            }
+        }
+        return;
+    }
+    if constexpr (LNF == 2) {            // LayerNorm(X) folded in
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            f4 col[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
+            gemm_epilogue_row<NF, 2>(p, col, m0 + wm * 16 * MF + j * 16 + l15, n0 + wn * NF * 16, g, nullptr, 0, lnrow[j]);
+        }
+        return;
+    }
+    if constexpr (LNF == 1) {            // row statistics of the stored outputs: lanes g = 0..3 of a row, then the two wave columns (fixed order)
+        static_assert(NF == 5 && MF == 4, "the statistics slot is the block's 160 columns");
+        float2* xs = reinterpret_cast<float2*>(smem);      // [128 rows] partials of wave column 1
+        __syncthreads();                                    // every wave is done with the operand tiles
+#pragma unroll
+        for (int j = 0; j < MF; ++j) {
+            const int row = wm * 16 * MF + j * 16 + l15;
+            f4 col[NF];
+#pragma unroll
+            for (int i = 0; i < NF; ++i) col[i] = acc[i][j];
+            float2 st = float2{0.f, 0.f};
+            gemm_epilogue_row<NF, 1>(p, col, m0 + row, n0 + wn * NF * 16, g, nullptr, 0, float2{0.f, 1.f}, &st);
+            st.x += __shfl_xor(st.x, 16, 64);
+            st.y += __shfl_xor(st.y, 16, 64);
+            st.x += __shfl_xor(st.x, 32, 64);
+            st.y += __shfl_xor(st.y, 32, 64);
+            if (wn == 1 && g == 0) xs[row] = st;
+            acc[0][j][0] = st.x;                            // kept for the second pass (wave column 0)
+            acc[0][j][1] = st.y;
+        }
+        __syncthreads();
+        if (wn == 0 && g == 0) {
+#pragma unroll
+            for (int j = 0; j < MF; ++j) {
+                const int row = wm * 16 * MF + j * 16 + l15;
+                const int m = m0 + row;
+                if (m < p.M) {
+                    const float2 o = xs[row];
+                    *reinterpret_cast<float2*>(p.stats_out + ((long)m * (p.N / 160) + n0 / 160) * 2) = float2{acc[0][j][0] + o.x, acc[0][j][1] + o.y};
+                }
             }
         }
         return;
@@ -1185,6 +1272,61 @@ bool uv_linear_takes_big_direct(long M, int N, int K, long ldx) {
     return n256 >= big_env().bigmin && n192 >= big_env().bigmin;      // whichever tile height the launcher picks
 }
 
+// ONE copy of how the 128-wide path tiles a problem and whether it would split K (used by the launcher and by the fold predicates).
+struct SmallPlan {
+    bool nf5, small_m;
+    int bn, nt, splits;
+};
+static SmallPlan small_plan(long M, int N, int K, bool geglu, int mode, bool want_stats) {
+    SmallPlan sp;
+    // NF = 5 (160-column tiles) for widths that 160 divides and 128 does not — and for every producer of row statistics: the
+    // block's 160 columns are then exactly one statistics slot
+    sp.nf5 = !geglu && (N % 160 == 0) && ((N % 128 != 0) || want_stats);
+    sp.bn = sp.nf5 ? 160 : 128;
+    sp.nt = (int)(((M + BM_DEFAULT - 1) / BM_DEFAULT) * ((N + sp.bn - 1) / sp.bn));
+    // small-M problems (deepest UNet level: 3072 rows): 64-row tiles double the block count so the chip is filled
+    // UNIVST_GEMM_SMALLM (A/B aid): 0 = never, 1 = whenever the 128-row tiles are < 2 per CU, 2 (default) = convs only when
+    // split-K cannot supply the parallelism instead (short K); linears always (measured: tools/bench_gemm_mid.py)
+    static const int smallm_mode = getenv("UNIVST_GEMM_SMALLM") ? atoi(getenv("UNIVST_GEMM_SMALLM")) : 2;
+    sp.small_m = !sp.nf5 && sp.nt < 2 * uv_num_cus() && M > 64 && smallm_mode != 0 &&
+                 (smallm_mode == 1 || mode == 0 || geglu || (K + 63) / 64 < 16);
+    if (sp.small_m) sp.nt = (int)(((M + 63) / 64) * ((N + sp.bn - 1) / sp.bn));
+    // split-K when the tiles alone leave most CUs idle and K is long (deep levels; every level of a frame shard)
+    sp.splits = 1;
+    static const int splitk = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
+    if (splitk && !geglu && N % 4 == 0 && sp.nt < 384) {
+        const int nk = (K + 63) / 64;
+        const int s = uv_pick_splits(sp.nt, nk, 2L * uv_num_cus(), 4, 16, 1.0, (double)M * N * 4.0);     // two resident blocks per CU
+        if (s >= 2) sp.splits = s;
+    }
+    return sp;
+}
+
+// May a LayerNorm be folded around a plain linear [M, K] x [N, K]^T?  As the PRODUCER of the normalised tensor it has to leave the row
+// statistics of its output (one slot per 160 columns), as the CONSUMER it applies them in its epilogue.  Both exist in the direct
+// 256x320 kernel and, since round 4, in the 128-wide kernel when that runs the problem without split-K (the epilogue of a split
+// problem lives in the reduction kernel).  The GEGLU consumer exists in the 256x320 kernel only.
+bool uv_linear_fold_producer_ok(long M, int N, int K) {
+    if (uv_linear_takes_big_direct(M, N, K)) return true;
+    static const int env = getenv("UNIVST_LN_FOLD_SMALL") ? atoi(getenv("UNIVST_LN_FOLD_SMALL")) : 1;
+    if (!env || N % 160 != 0 || K % 8 != 0) return false;
+    if (big_shape_ok(N, K, M * (long)K)) {      // the 256x320 path with split-K would take it (long reductions): no epilogue there
+        const long n256 = ((M + 255) / 256) * (N / 320);
+        if (n256 >= 8 && K >= 128 * 64) return false;
+    }
+    return small_plan(M, N, K, false, 0, true).splits == 1;
+}
+bool uv_linear_fold_consumer_ok(long M, int N, int K, bool geglu) {
+    if (uv_linear_takes_big_direct(M, N, K)) return true;
+    static const int env = getenv("UNIVST_LN_FOLD_SMALL") ? atoi(getenv("UNIVST_LN_FOLD_SMALL")) : 1;
+    if (!env || geglu || N % 4 != 0 || K % 160 != 0) return false;
+    if (big_shape_ok(N, K, M * (long)K)) {
+        const long n256 = ((M + 255) / 256) * (N / 320);
+        if (n256 >= 8 && K >= 128 * 64) return false;
+    }
+    return small_plan(M, N, K, false, 0, false).splits == 1;
+}
+
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     const bool lnf = p.ln_stats || p.stats_out;
@@ -1328,43 +1470,43 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
             return UV_OK;
         }
     }
-    UV_REQUIRE(!lnf, "linear: LayerNorm fold requested for M=%d N=%d K=%d, which the 256x320 path does not take (uv_linear_takes_big_direct)", p.M, p.N, p.K);
-    bool nf5 = !p.geglu && (p.N % 160 == 0) && (p.N % 128 != 0) ;
-    int BN = nf5 ? 160 : 128;
-    int nt = ((p.M + BM_DEFAULT - 1) / BM_DEFAULT) * ((p.N + BN - 1) / BN);
-    // small-M problems (deepest UNet level: 3072 rows): 64-row tiles double the block count so the chip is filled
-    // UNIVST_GEMM_SMALLM (A/B aid): 0 = never, 1 = whenever the 128-row tiles are < 2 per CU, 2 (default) = convs only when
-    // split-K cannot supply the parallelism instead (short K); linears always (measured: tools/bench_gemm_mid.py)
-    static const int smallm_mode = getenv("UNIVST_GEMM_SMALLM") ? atoi(getenv("UNIVST_GEMM_SMALLM")) : 2;
-    const bool small_m = !nf5 && nt < 2 * uv_num_cus() && p.M > 64 && smallm_mode != 0 &&
-                         (smallm_mode == 1 || mode == 0 || p.geglu || (p.K + 63) / 64 < 16);
-    if (small_m) nt = ((p.M + 63) / 64) * ((p.N + BN - 1) / BN);
+    const SmallPlan plan = small_plan(p.M, p.N, p.K, p.geglu != 0, mode, p.stats_out != nullptr);
+    if (lnf) {
+        UV_REQUIRE(mode == 0 && !p.geglu && !p.act && !p.gate && plan.splits == 1 && !(p.ln_stats && p.stats_out) &&
+                   (!p.stats_out || (plan.nf5 && p.N % 160 == 0)) &&
+                   (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0 && p.N % 4 == 0)),
+                   "linear: LayerNorm fold requested for M=%d N=%d K=%d, which neither the direct 256x320 path nor the 128-wide path without split-K takes "
+                   "(uv_linear_fold_producer_ok / uv_linear_fold_consumer_ok)", p.M, p.N, p.K);
+    }
+    const bool nf5 = plan.nf5, small_m = plan.small_m;
+    int nt = plan.nt;
     if (p.geglu) UV_REQUIRE(p.N % 32 == 0, "geglu: N=%d must be a multiple of 32", p.N);
-    // split-K when the tiles alone leave most CUs idle and K is long (deep levels; every level of a frame shard)
     GemmParams q = p;
     q.splits = 1;
     bool own_ws = false;
-    static const int splitk = getenv("UNIVST_GEMM_SPLITK") ? atoi(getenv("UNIVST_GEMM_SPLITK")) : 1;
-    if (splitk && !p.geglu && p.N % 4 == 0 && nt < 384) {
+    if (plan.splits >= 2) {
         const int nk = (p.K + 63) / 64;
-        const int s = uv_pick_splits(nt, nk, 2L * uv_num_cus(), 4, 16, 1.0, (double)p.M * p.N * 4.0);     // two resident blocks per CU
-        if (s >= 2) {
-            q.ktps = (nk + s - 1) / s;
-            q.splits = (nk + q.ktps - 1) / q.ktps;
-            const size_t need = (size_t)q.splits * p.M * p.N * sizeof(float);
-            if (q.partial && q.partial_bytes >= need) {
-            } else if (need <= UV_SPLITK_WS_BYTES) {   // stand-alone operator call: stream-ordered scratch
-                UV_HIP(hipMallocAsync((void**)&q.partial, need, stream));
-                own_ws = true;
-            } else {
-                q.splits = 1;
-            }
+        q.ktps = (nk + plan.splits - 1) / plan.splits;
+        q.splits = (nk + q.ktps - 1) / q.ktps;
+        const size_t need = (size_t)q.splits * p.M * p.N * sizeof(float);
+        if (q.partial && q.partial_bytes >= need) {
+        } else if (need <= UV_SPLITK_WS_BYTES) {   // stand-alone operator call: stream-ordered scratch
+            UV_HIP(hipMallocAsync((void**)&q.partial, need, stream));
+            own_ws = true;
+        } else {
+            q.splits = 1;
         }
     }
     dim3 grid(nt * q.splits), block(256);
     uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
                   2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
-    if (small_m) {
+    if (p.stats_out) {
+        hipLaunchKernelGGL((gemm_kernel<5, 0, 4, 1>), grid, block, 0, stream, q);
+    } else if (p.ln_stats) {
+        if (small_m) hipLaunchKernelGGL((gemm_kernel<4, 0, 2, 2>), grid, block, 0, stream, q);
+        else if (nf5) hipLaunchKernelGGL((gemm_kernel<5, 0, 4, 2>), grid, block, 0, stream, q);
+        else hipLaunchKernelGGL((gemm_kernel<4, 0, 4, 2>), grid, block, 0, stream, q);
+    } else if (small_m) {
         if (mode == 0) hipLaunchKernelGGL((gemm_kernel<4, 0, 2>), grid, block, 0, stream, q);
         else hipLaunchKernelGGL((gemm_kernel<4, 1, 2>), grid, block, 0, stream, q);
     } else if (mode == 0) {

@@ -39,7 +39,7 @@ struct GemmParams {
     int splits = 1, ktps = 0;          // set by the launcher
     int tile_gn = 0, tile_gm = 0;      // 256x320 kernel: tile order in groups of tile_gm row tiles x tile_gn column tiles (0: column tile fastest); set by the launcher
     int issue_mode = 0;                // 256x320 kernel, A/B aid: how the next tile's DMA is spread over the current tile's MFMAs
-    // LayerNorm folded into the linears around it (256x320 direct path only, uv_linear_takes_big_direct):
+    // LayerNorm folded into the linears around it (uv_linear_fold_producer_ok / uv_linear_fold_consumer_ok):
     //  producer: stats_out[m][N/160][2] <- (sum, sum of squares) of the stored fp16 outputs per 160-column slot;
     //  consumer: X holds the RAW rows, W = gamma (.) W, and the epilogue computes rstd*(acc - mean*ln_wsum[n]) + ln_bias[n]
     //            with (mean, rstd) over K from ln_stats[m][ln_slots][2]  (ln_bias already contains the linear's own bias).
@@ -85,6 +85,10 @@ struct AttnParams {
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
 bool uv_linear_takes_big_direct(long M, int N, int K, long ldx = 0);
+// LayerNorm fold around a plain linear: may it emit the row statistics of its output / apply those of its input?  (256x320 direct path,
+// or the 128-wide path when that runs the problem without split-K; the GEGLU consumer is 256x320 only)
+bool uv_linear_fold_producer_ok(long M, int N, int K);
+bool uv_linear_fold_consumer_ok(long M, int N, int K, bool geglu);
 constexpr size_t UV_SPLITK_WS_BYTES = 128u << 20;  // fp32 partials [splits][M][N]: 8 splits of the 8x8-level convs (3072 x 1280)
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);

@@ -873,8 +873,13 @@ struct Fwd {
         // statistics, the consuming one runs on the raw rows — no LayerNorm launch, no normalised copy in HBM.
         // norm3 -> GEGLU projection is folded only on request (ln_fold = 2): its epilogue is the longest of the block and the fold
         // costs it more than the LayerNorm launch it removes (tools/bench_ln_fold.py).
-        const bool fold = u.ln_fold > 0 && C % 160 == 0 && uv_linear_takes_big_direct(rows, C, C) && uv_linear_takes_big_direct(rows, 3 * C, C);
-        const bool fold3 = fold && u.ln_fold > 1 && uv_linear_takes_big_direct(rows, 8 * C, C);
+        // (round 4: also on the 128-wide kernel where that runs these linears without split-K — the 64x64 / 32x32 levels of a frame shard)
+        const bool fold = u.ln_fold > 0 && C % 160 == 0 && uv_linear_fold_producer_ok(rows, C, C) && uv_linear_fold_consumer_ok(rows, 3 * C, C, false) &&
+                          uv_linear_fold_consumer_ok(rows, C, C, false);
+        // norm3 with the statistics from a 128-wide producer: UNIVST_LN_FOLD_SMALL=1 leaves it a LayerNorm launch (A/B: emulated rank of 8,
+        // F = 16: 12.83 ms per step without the 128-wide fold, 12.81 with norm1 / norm2 only, 12.70 with all three)
+        static const int fold_small = getenv("UNIVST_LN_FOLD_SMALL") ? atoi(getenv("UNIVST_LN_FOLD_SMALL")) : 2;
+        const bool fold3 = fold && u.ln_fold > 1 && uv_linear_fold_consumer_ok(rows, 8 * C, C, true) && (fold_small > 1 || uv_linear_takes_big_direct(rows, C, C));
         float* lnst = fold ? (float*)alloc(rows * (C / 160) * 4) : nullptr;      // [rows][C/160][2] fp32
         if (fold && !lnst) return UV_ERR_STATE;
         RUN(linear(t0, C, rows, C, p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight"), p + ".proj_in.bias", C, h, C,
