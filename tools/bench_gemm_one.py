@@ -5,5 +5,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "ff1"
 if which == "ff1": lin(196608, 2560, 320, geglu=True, tag="L0 ff1")
 elif which == "proj": lin(196608, 320, 320, res=True, tag="L0 proj")
 elif which == "qkv": lin(196608, 960, 320, tag="L0 qkv")
+elif which == "ff2": lin(196608, 320, 1280, res=True, tag="L0 ff2")
+elif which == "l2qkv": lin(12288, 3840, 1280, tag="L2 qkv")
 elif which == "conv": conv_ti(320, 320, 64)
 elif which == "convp": conv_patch(320, 320, 64)

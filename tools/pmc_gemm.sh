@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the 192x320 conv kernel on the 320 -> 320 64x64 layer (tools/bench_gemm_one.py $2: convp = LDS-patch kernel
+# SQ counters of one GEMM-class launch (tools/bench_gemm_one.py $2: ff1 / ff2 / qkv / l2qkv = linears of the 256x320 kernel, convp = LDS-patch kernel
 # (default), conv = tap-inner im2col kernel); counters only.
 cd /tmp && export TMPDIR=/tmp
 OUT=${1:-$GRAFT_REPO_ROOT/gpurun_out/pmc_gemm}

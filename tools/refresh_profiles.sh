@@ -15,6 +15,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/raw/fetch --
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/raw/write -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/raw/write.log 2>&1
 bash tools/pmc_attn.sh $O/raw/attn > $O/round${ROUND}_pmc_attn_d40_sq.txt 2>&1
 bash tools/pmc_gemm.sh $O/raw/gemm convp 2>&1 | grep -E "^SQ_" > $O/round${ROUND}_pmc_conv_patch_sq.txt
+# the dominant class by shape: the K = 320 GEGLU projection (fixed-cost bound) and a long-K linear of the same kernel
+for w in ff1 l2qkv ff2; do echo "== $w"; bash tools/pmc_gemm.sh $O/raw/gemm_$w $w 2>&1 | grep -E "^SQ_"; done > $O/round${ROUND}_pmc_gemm_big_sq_raw.txt
 for w in inversion inversion_pair transfer_nomask maskprop warp; do python bench.py --workload $w --no-cpu-baseline > $O/round${ROUND}_bench_$w.json 2>> $O/raw/bench.err; done
 python bench.py --frames 32 --emulate-rank 0/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank0of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8.json 2>> $O/raw/bench.err
