@@ -113,6 +113,32 @@ __device__ __forceinline__ f2 geglu_erf2(f2 x, f2 g) {
     return __builtin_elementwise_fma(t, S, t);
 }
 
+// the same for two pairs with the two Horner chains interleaved link by link: a dependent v_pk_fma_f32 needs one wait state after its
+// producer, and hipcc (at 245-251 VGPRs) schedules the chains of a block one after the other, padding every link of the second with an s_nop
+__device__ __forceinline__ void geglu_erf2x2(f2 xa, f2 ga, f2 xb, f2 gb, f2& ya, f2& yb) {
+    f2 ca, cb;
+    ca.x = __builtin_amdgcn_fmed3f(ga.x, -5.f, 5.f);
+    ca.y = __builtin_amdgcn_fmed3f(ga.y, -5.f, 5.f);
+    cb.x = __builtin_amdgcn_fmed3f(gb.x, -5.f, 5.f);
+    cb.y = __builtin_amdgcn_fmed3f(gb.y, -5.f, 5.f);
+    const f2 sa = __builtin_elementwise_fma(ca * 0.08f, ca, f2{-1.f, -1.f});
+    const f2 sb = __builtin_elementwise_fma(cb * 0.08f, cb, f2{-1.f, -1.f});
+    constexpr float c[13] = {2.827276369e-01f, -1.405918177e-01f, 1.030358595e-01f, -8.090256480e-02f, 6.295351729e-02f, -4.642625655e-02f,
+                             3.247217962e-02f, -2.261424982e-02f, 1.353305501e-02f, -5.053833458e-03f, 2.749192302e-03f, -3.353461957e-03f,
+                             1.470752778e-03f};
+    f2 pa = f2{c[12], c[12]}, pb = f2{c[12], c[12]};
+#pragma unroll
+    for (int i = 11; i >= 0; --i) {
+        pa = __builtin_elementwise_fma(pa, sa, f2{c[i], c[i]});
+        pb = __builtin_elementwise_fma(pb, sb, f2{c[i], c[i]});
+        __builtin_amdgcn_sched_barrier(0);              // keep the two chains alternating
+    }
+    const f2 Sa = ca * pa, Sb = cb * pb;
+    const f2 ta = (xa * 0.5f) * ga, tb = (xb * 0.5f) * gb;
+    ya = __builtin_elementwise_fma(ta, Sa, ta);
+    yb = __builtin_elementwise_fma(tb, Sb, tb);
+}
+
 // XCD-aware bijective block remap (8 XCDs, block b observed on XCD b%8): consecutive logical ids
 // land on the same XCD so tiles that share an operand panel hit the same 4 MiB L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -464,11 +464,11 @@ __device__ __forceinline__ void gemm_epilogue_geglu_slab(const GemmParams& p, co
                     gv[r] = fmaf(ln.y, fmaf(-ln.x, wg[r], acc[i + 1][j][r]), cg[r]);
                 }
             } else {
-                h4 bx = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-                if (p.bias) {
-                    bx = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4);
-                    bg = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4 + 16);
-                }
+                // (no `if (p.bias)` here: epi_const_stage stages zeros for a missing bias, and a branch per 16-column block made every block
+                // its own basic block — hipcc then cannot interleave the dependent v_pk_fma_f32 chains of two blocks and pads each link
+                // with an s_nop: 423 of them per tile and wave)
+                const h4 bx = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4);
+                const h4 bg = *reinterpret_cast<const h4*>(hb + i * 16 + g * 4 + 16);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     xv[r] = acc[i][j][r] + (float)bx[r];
@@ -476,12 +476,18 @@ __device__ __forceinline__ void gemm_epilogue_geglu_slab(const GemmParams& p, co
                 }
             }
             h4 o;
+#ifdef UV_GEGLU_X1
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
                 const f2 y = geglu_erf2(f2{xv[r], xv[r + 1]}, f2{gv[r], gv[r + 1]});
                 o[r] = (half_t)y.x;
                 o[r + 1] = (half_t)y.y;
             }
+#else
+            f2 y0, y1;
+            geglu_erf2x2(f2{xv[0], xv[1]}, f2{gv[0], gv[1]}, f2{xv[2], xv[3]}, f2{gv[2], gv[3]}, y0, y1);
+            o[0] = (half_t)y0.x; o[1] = (half_t)y0.y; o[2] = (half_t)y1.x; o[3] = (half_t)y1.y;
+#endif
             *reinterpret_cast<h4*>(&slab[(j * 16 + l15) * GEGLU_SLD + (i / 2) * 16 + g * 4]) = o;
         }
     }
