@@ -124,10 +124,16 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
-/* Y[M,N] = X[M,K] W[N,K]^T + bias + residual; geglu: W rows must be pre-interleaved, writes N/2 columns.
+/* Y[M,N] = X[M,K] W[N,K]^T + bias + residual; geglu != 0: the diffusers GEGLU projection (FeedForward net[0], attention.py:241) — writes the
+ * N/2 columns x * gelu(gate), W / bias rows pre-interleaved: geglu = 1 in blocks of [16 x rows | 16 gate rows] (any K), geglu = 2 in the
+ * order of the X-resident kernel for K = 320 (N % 256 == 0, no residual; univst_geglu_xres_permute makes it from the [x | gate] weight).
  * Replaces torch Linear / 1x1 conv call sites attention.py:123,141,375-377,425. */
 int univst_linear(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr,
                   void* Y, int64_t ldy, int M, int N, int K, int geglu, void* stream);
+/* Row permutation of a GEGLU projection's weight [rows][cols] (or bias / per-row fp16 vector: cols = 1) from the checkpoint's
+ * [x rows | gate rows] order into the geglu = 2 order: row nt*256 + wn*64 + i*16 + g*4 + r <- x row (r < 2) or gate row (r >= 2) of hidden
+ * column nt*128 + wn*32 + i*8 + g*2 + (r & 1).  rows % 256 == 0. */
+int univst_geglu_xres_permute(const void* in, void* out, int rows, int cols, void* stream);
 /* The linear with the MM-DiT epilogues of the SD3 path (diffusers JointTransformerBlock / FeedForward, third-party):
  *   Y = residual + gate[m / rows_per_gate] (.) act(X W^T + bias)
  * act: UNIVST_ACT_NONE or UNIVST_ACT_GELU_TANH (defined below); gate (may be NULL): rows of N halfs, ld_gate apart, 16-byte aligned

@@ -74,6 +74,43 @@ def test_linear_geglu(nat):
     close(nat.linear(x, w[idx].contiguous(), bias=b[idx].contiguous(), geglu=True), ref)
 
 
+def _xres_source_rows(N):
+    """row n of the X-resident GEGLU order <- row of the [x rows | gate rows] weight (include/univst.h, univst_geglu_xres_permute)"""
+    n = torch.arange(N)
+    nt, wn, i, g, r = n // 256, (n % 256) // 64, (n % 64) // 16, (n % 16) // 4, n % 4
+    h = nt * 128 + wn * 32 + i * 8 + g * 2 + (r & 1)
+    return torch.where(r < 2, h, N // 2 + h)
+
+
+@pytest.mark.parametrize("M,N", [(4096 + 37, 2560), (24576, 2560), (100, 256), (65536, 512)])
+def test_linear_geglu_x_resident(nat, M, N):
+    """geglu = 2: the K = 320 projection on the kernel that keeps a block's 128 activation rows in LDS and streams the weights once per
+    row block (weight rows interleaved [x0 x1 g0 g1 ...] by univst_geglu_xres_permute).  Reference: torch fp32 linear -> x * gelu(gate);
+    ragged M, a single column tile, the row count of one frame-shard rank and the FF1 width of the 64x64 level."""
+    K = 320
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3)
+    src = _xres_source_rows(N).cuda()
+    wp, bp = nat.geglu_xres_permute(w), nat.geglu_xres_permute(b)
+    assert torch.equal(wp, w[src]) and torch.equal(bp, b[src]), "the permutation kernel and the documented row order differ"
+    h = x.float() @ w.float().T + b.float()
+    a, gate = h.chunk(2, dim=-1)
+    close(nat.linear(x, wp, bias=bp, geglu=2), a * F.gelu(gate))
+    close(nat.linear(x, wp, geglu=2), (x.float() @ w.float().T).chunk(2, dim=-1)[0] * F.gelu((x.float() @ w.float().T).chunk(2, dim=-1)[1]))
+    # same values as the 256x320 / 128-wide GEGLU kernels up to fp16 rounding of identical fp32 math: compare directly as well
+    idx = []
+    for q in range(N // 32):
+        idx += list(range(16 * q, 16 * q + 16)) + list(range(N // 2 + 16 * q, N // 2 + 16 * q + 16))
+    idx = torch.tensor(idx).cuda()
+    other = nat.linear(x, w[idx].contiguous(), bias=b[idx].contiguous(), geglu=True)
+    assert (nat.linear(x, wp, bias=bp, geglu=2).float() - other.float()).abs().max().item() <= 2e-3 * other.float().abs().max().item()
+
+
+def test_linear_geglu_x_resident_rejects_other_shapes(nat):
+    x, w = rnd(512, 640, seed=1), rnd(2560, 640, seed=2)
+    with pytest.raises(RuntimeError, match="K = 320"):
+        nat.linear(x, w, geglu=2)
+
+
 def test_linear_big_tile_path(nat):
     """shapes that dispatch to the 256x320 GLDS kernel (>= 150 tiles), incl. M tail, K tail, bias+residual, GEGLU."""
     M = 131072 + 77
@@ -612,6 +649,35 @@ def test_linear_layernorm_fold(nat, M, C, Nf, geglu, res, row_mean):
         y = y + r.float()
     scale = y.abs().max().item()
     mx = (got - y).abs().max().item() / scale
+    rms = ((got - y).pow(2).mean().sqrt() / y.pow(2).mean().sqrt()).item()
+    assert mx < 2e-3 and rms < 5e-4, (mx, rms)
+
+
+@pytest.mark.parametrize("M,row_mean", [(49152, 0.7), (6144 + 5, 30.0)])
+def test_linear_geglu_x_resident_layernorm_fold(nat, M, row_mean):
+    """norm3 folded into the X-resident GEGLU projection (K = 320): statistics from a producer linear, gamma folded into the permuted
+    weight, wsum / lnb in the permuted row order.  Same reference and bars as test_linear_layernorm_fold."""
+    C, Nf = 320, 2560
+    g = torch.Generator().manual_seed(M)
+    x0 = torch.randn(M, C, generator=g).half().cuda()
+    wp_ = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    bp_ = (row_mean + 0.3 * torch.randn(C, generator=g)).half().cuda()
+    stats = torch.zeros(M, C // 160, 2, device="cuda", dtype=torch.float32)
+    x = nat.linear_ln(x0, wp_, bias=bp_, stats_out=stats)
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).half().cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).half().cuda()
+    w = (torch.randn(Nf, C, generator=g) / math.sqrt(C)).half().cuda()
+    b = (0.1 * torch.randn(Nf, generator=g)).half().cuda()
+    src = _xres_source_rows(Nf).cuda()
+    wx, bx = w[src].contiguous(), b[src].contiguous()
+    wl = (wx.float() * gamma.float()[None]).half()
+    wsum = wl.float().sum(1).contiguous()
+    lnb = (bx.float() + wx.float() @ beta.float()).contiguous()
+    got = nat.linear_ln(x, wl, geglu=2, ln=(stats, wsum, lnb)).float()
+    xn = torch.nn.functional.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    a, gate = (xn @ w.float().t() + b.float()).chunk(2, dim=-1)
+    y = a * F.gelu(gate)
+    mx = (got - y).abs().max().item() / y.abs().max().item()
     rms = ((got - y).pow(2).mean().sqrt() / y.pow(2).mean().sqrt()).item()
     assert mx < 2e-3 and rms < 5e-4, (mx, rms)
 

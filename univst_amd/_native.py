@@ -64,6 +64,7 @@ SIGNATURES = {
     "univst_unet_set_comm_native": (_I, [_P, _P]),
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "univst_linear_ln": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
+    "univst_geglu_xres_permute": (_I, [_P, _P, _I, _I, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv3x3_patch": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
@@ -147,7 +148,8 @@ def _f16(t: torch.Tensor, name="tensor"):
 
 # --------------------------------------------------------------------------- stand-alone operator wrappers
 def linear(x, w, bias=None, residual=None, geglu=False, out=None):
-    """y[M,N] = x[M,K] w[N,K]^T (+bias)(+residual); geglu: w/bias rows pre-interleaved, N/2 output columns."""
+    """y[M,N] = x[M,K] w[N,K]^T (+bias)(+residual); geglu: w/bias rows pre-interleaved (True / 1: [16 x | 16 gate] blocks; 2: the
+    X-resident order for K = 320, see geglu_xres_permute), N/2 output columns."""
     _f16(x), _f16(w)
     M, K = x.shape
     N = w.shape[0]
@@ -168,6 +170,16 @@ def linear_gated(x, w, bias=None, residual=None, act=None, gate=None, rows_per_g
         out = torch.empty(M, N, device=x.device, dtype=torch.float16)
     check(load().univst_linear_gated(ptr(x), K, ptr(w), ptr(bias), ptr(residual), N, ptr(out), N, M, N, K, -1 if act is None else act,
                                      ptr(gate), 0 if gate is None else _mod_ld(gate), rows_per_gate, stream_ptr()), "linear_gated")
+    return out
+
+
+def geglu_xres_permute(w):
+    """GEGLU projection weight [N, K] (or bias [N]) from the checkpoint's [x rows | gate rows] order into the row order ``linear(...,
+    geglu=2)`` expects (the X-resident kernel for K = 320)."""
+    _f16(w)
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    check(load().univst_geglu_xres_permute(ptr(w), ptr(out), w.shape[0], 1 if w.dim() == 1 else w.shape[1], stream_ptr()), "geglu_xres_permute")
     return out
 
 

@@ -130,12 +130,16 @@ int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* b
     g.gate = H(gate); g.ld_gate = ld_gate; g.rows_per_gate = gate ? rows_per_gate : 1;
     return uv_launch_gemm(g, 0, S(s));
 }
+int univst_geglu_xres_permute(const void* in, void* out, int rows, int cols, void* s) {
+    UV_REQUIRE(in && out, "geglu_xres_permute: null argument");
+    return uv_launch_geglu_xres_permute(H(in), HM(out), rows, cols, S(s));
+}
 int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                      int M, int N, int K, int geglu, const float* ln_stats, float ln_eps, const float* ln_wsum, const float* ln_bias,
                      float* stats_out, void* s) {
     UV_REQUIRE(X && W && Y, "linear_ln: null argument");
     UV_REQUIRE(!ln_stats || (ln_wsum && ln_bias && K % 160 == 0 && !bias), "linear_ln: a folded LayerNorm needs wsum, lnb (which holds the bias) and K %% 160 == 0");
-    UV_REQUIRE((!stats_out || uv_linear_fold_producer_ok(M, N, K)) && (!ln_stats || uv_linear_fold_consumer_ok(M, N, K, geglu != 0)),
+    UV_REQUIRE((!stats_out || uv_linear_fold_producer_ok(M, N, K)) && (!ln_stats || geglu == 2 || uv_linear_fold_consumer_ok(M, N, K, geglu != 0)),
                "linear_ln: M=%d N=%d K=%d is not taken by the direct 256x320 path (N %% 320 == 0 and >= 150 tiles) nor by the 128-wide path without split-K", M, N, K);
     GemmParams g;
     g.X = H(X); g.ldx = ldx; g.W = H(W); g.bias = H(bias); g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy;

@@ -508,6 +508,160 @@ __device__ __forceinline__ void gemm_epilogue_geglu_slab(const GemmParams& p, co
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// X-RESIDENT GEGLU projection for K = 320 (round 4: the FF1 of the 64x64 level — the largest single shape of the step).
+//
+// The 256x320 tile spends 13 of its 23 us at K = 320 outside the k loop (prologue / drain, GELU, store tail) and re-streams the
+// activation rows once per column tile.  Here a block owns 128 rows, DMAs their 320 activations into LDS ONCE (80 KB) and walks all
+// column tiles of N (256 columns each) with only the weights streaming through two 32 KB buffers — the weight stream never drains
+// between column tiles, and the next tile's first k tile is in flight under this tile's epilogue.  Waves 2(m) x 4(n), 64x64 register
+// tiles (64 accumulators).  Weight rows are pre-interleaved [x0 x1 g0 g1 | x2 x3 g2 g3 ...] per 16-row fragment
+// (geglu_xres_permute_kernel, `GemmParams::geglu == 2`): a lane's accumulator quad is two whole (x, gate) pairs, so the math stays in
+// the MFMA register layout, and the fp16 products of a 16-row fragment leave through a 1.25 KB slab per wave as 16-byte pieces.
+// Column tile nt, wave column wn, fragment i, lane group g, register r  <->  weight row nt*256 + wn*64 + i*16 + g*4 + r:
+//     r < 2: x row of hidden column h = nt*128 + wn*32 + i*8 + g*2 + r;  r >= 2: the gate row of h (r - 2).
+// bias / ln_wsum / ln_bias are indexed by that weight row order too.  LNF = 2: the LayerNorm of X folded in (see gemm_epilogue_row).
+// Measured stand-alone (tools/probes/xres_probe.hip, M = 196 608, N = 2 560): 0.443 ms = 728 TFLOP/s against 0.556 ms = 580 for the
+// 256x320 tile; issuing the previous column tile's epilogue between this tile's MFMAs (a second accumulator set) was slower (0.47 ms).
+constexpr int XR_BM = 128, XR_BN = 256, XR_K = 320, XR_NKT = XR_K / 64;
+constexpr int XR_XS = XR_NKT * XR_BM * 64, XR_WT = XR_BN * 64, XR_SLAB = 16 * 40;
+__host__ __device__ inline int geglu_xres_source_row(int n, int N) {      // which row of the [x | gate] weight is row n of the interleaved one
+    const int nt = n / 256, wn = (n % 256) / 64, i = (n % 64) / 16, g = (n % 16) / 4, r = n % 4;
+    const int h = nt * 128 + wn * 32 + i * 8 + g * 2 + (r & 1);
+    return r < 2 ? h : N / 2 + h;
+}
+template <int LNF>
+__global__ __launch_bounds__(512, 2) void geglu_xres_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) half_t smem[XR_XS + 2 * XR_WT + 8 * XR_SLAB];      // ONE LDS object (see gemm_big_kernel)
+    half_t* const Xs = smem;
+    half_t* const Wb = smem + XR_XS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, g = lane >> 4;
+    half_t* const slab = smem + XR_XS + 2 * XR_WT + wave * XR_SLAB;
+    const int m0 = blockIdx.x * XR_BM;
+    const int NT = p.N / XR_BN;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto glds16 = [&](const half_t* src, half_t* dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    const int rb = tid >> 3, kc = (tid & 7) ^ (rb & 7);
+    // ---- the block's activations, once: k tile kt = 128 rows of 128 B, 16-byte chunks XOR-swizzled with (row & 7)
+#pragma unroll
+    for (int kt = 0; kt < XR_NKT; ++kt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + rb + 64 * i;
+            glds16(m < p.M ? p.X + (long)m * p.ldx + kt * 64 + kc * 8 : uv_zero_page, Xs + kt * XR_BM * 64 + (64 * i + wave_u * 8) * 64);
+        }
+    auto issue_w = [&](int nt, int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(p.W + (long)(nt * XR_BN + rb + 64 * i) * XR_K + kt * 64 + kc * 8, Wb + buf * XR_WT + (64 * i + wave_u * 8) * 64);
+    };
+    issue_w(0, 0, 0);
+    // (mean, rstd) of the lane's four rows (LNF == 2), under the first DMAs
+    float2 lnrow[LNF == 2 ? 4 : 1];
+    if constexpr (LNF == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 64 + j * 16 + l15;
+            float s1 = 0.f, s2 = 0.f;
+            if (m < p.M) {
+                const float2* sp = reinterpret_cast<const float2*>(p.ln_stats) + (long)m * p.ln_slots;
+                for (int e = 0; e < p.ln_slots; ++e) {
+                    const float2 t = sp[e];
+                    s1 += t.x;
+                    s2 += t.y;
+                }
+            }
+            const float mean = s1 * (1.f / XR_K);
+            const float var = fmaxf(fmaf(-mean, mean, s2 * (1.f / XR_K)), 0.f);
+            lnrow[j] = float2{mean, rsqrtf(var + p.ln_eps)};
+        }
+    }
+    const int sw = l15 & 7;
+    for (int nt = 0; nt < NT; ++nt) {
+        // this tile's per-column constants of the lane (weight rows nt*256 + wn*64 + i*16 + g*4 .. +3), requested before the k loop
+        const int ncol = nt * XR_BN + wn * 64 + g * 4;
+        f4 cw[LNF == 2 ? 4 : 1], cb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (LNF == 2) {
+                cw[i] = *reinterpret_cast<const f4*>(p.ln_wsum + ncol + i * 16);
+                cb[i] = *reinterpret_cast<const f4*>(p.ln_bias + ncol + i * 16);
+            } else {
+                h4 b = {0, 0, 0, 0};
+                if (p.bias) b = *reinterpret_cast<const h4*>(p.bias + ncol + i * 16);
+                cb[i] = f4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+            }
+        }
+        f4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < XR_NKT; ++kt) {
+            const int step = nt * XR_NKT + kt;
+            __syncthreads();                  // vmcnt(0) + barrier: weight tile `step` (at step 0 also the activations) landed; the other buffer is free
+            if (kt + 1 < XR_NKT) issue_w(nt, kt + 1, (step + 1) & 1);
+            else if (nt + 1 < NT) issue_w(nt + 1, 0, (step + 1) & 1);
+            const half_t* Ws = Wb + (step & 1) * XR_WT;
+            const half_t* Xk = Xs + kt * XR_BM * 64;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int ch = ((ks * 4 + g) ^ sw) * 8;
+                h8 a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const h8*>(&Ws[(wn * 64 + i * 16 + l15) * 64 + ch]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const h8*>(&Xk[(wm * 64 + j * 16 + l15) * 64 + ch]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: row fragment j = 16 rows x 32 hidden columns of this wave
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                f4 va = acc[i][j], vb = acc[i + 1][j];
+                if constexpr (LNF == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        va[r] = fmaf(lnrow[j].y, fmaf(-lnrow[j].x, cw[i][r], va[r]), cb[i][r]);
+                        vb[r] = fmaf(lnrow[j].y, fmaf(-lnrow[j].x, cw[i + 1][r], vb[r]), cb[i + 1][r]);
+                    }
+                } else {
+                    va += cb[i];
+                    vb += cb[i + 1];
+                }
+                f2 ya, yb;
+                geglu_erf2x2(f2{va[0], va[1]}, f2{va[2], va[3]}, f2{vb[0], vb[1]}, f2{vb[2], vb[3]}, ya, yb);
+                *reinterpret_cast<h2*>(&slab[l15 * 40 + i * 8 + g * 2]) = h2{(half_t)ya.x, (half_t)ya.y};
+                *reinterpret_cast<h2*>(&slab[l15 * 40 + (i + 1) * 8 + g * 2]) = h2{(half_t)yb.x, (half_t)yb.y};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int row = lane >> 2, c = lane & 3;
+            const h8 v = *reinterpret_cast<const h8*>(&slab[row * 40 + c * 8]);
+            const int m = m0 + wm * 64 + j * 16 + row;
+            if (m < p.M) *reinterpret_cast<h8*>(p.Y + (long)m * p.ldy + nt * 128 + wn * 32 + c * 8) = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+// weight / bias rows of a GEGLU projection [x rows | gate rows] -> the interleaved order of geglu_xres_kernel (cols = 1: a bias vector)
+__global__ void geglu_xres_permute_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)rows * cols) return;
+    const int c = (int)(i % cols), r = (int)(i / cols);
+    out[i] = in[(long)geglu_xres_source_row(r, rows) * cols + c];
+}
 constexpr int BM_DEFAULT = 128;
 
 // Block tile BM x BN, 256 threads = 4 waves as 2(n) x 2(m); each wave NF x MF MFMA fragments.
@@ -1278,6 +1432,23 @@ bool uv_linear_takes_big_direct(long M, int N, int K, long ldx) {
     return n256 >= big_env().bigmin && n192 >= big_env().bigmin;      // whichever tile height the launcher picks
 }
 
+int uv_launch_geglu_xres_permute(const half_t* in, half_t* out, int rows, int cols, hipStream_t stream) {
+    UV_REQUIRE(rows % 256 == 0 && cols >= 1, "geglu_xres_permute: %d rows must be a multiple of 256", rows);
+    hipLaunchKernelGGL(geglu_xres_permute_kernel, dim3((unsigned)(((long)rows * cols + 255) / 256)), dim3(256), 0, stream, in, out, rows, cols);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+// M = 0: the shape alone (weight preparation).  With M: a block walks ALL column tiles of its 128 rows (74 us at N = 2 560), so the grid
+// has to fill whole rounds of the CUs: at least two rounds, the last one >= 80 % full — one rank of an 8-GPU job (192 blocks) and a 1.5-round
+// grid stay on the 256x320 tile (emulated rank: 1.34 vs 1.41 ms for the class).  UNIVST_GEGLU_XRES=0: never, =2: whenever the shape fits.
+bool uv_geglu_xres_ok(int N, int K, long M) {
+    static const int env = getenv("UNIVST_GEGLU_XRES") ? atoi(getenv("UNIVST_GEGLU_XRES")) : 1;
+    if (env == 0 || K != XR_K || N % XR_BN != 0) return false;
+    if (M <= 0 || env == 2) return true;
+    const long blocks = (M + XR_BM - 1) / XR_BM, ncu = uv_num_cus(), rounds = (blocks + ncu - 1) / ncu;
+    return blocks >= 2 * ncu && blocks * 10 >= rounds * ncu * 8;
+}
+
 // ONE copy of how the 128-wide path tiles a problem and whether it would split K (used by the launcher and by the fold predicates).
 struct SmallPlan {
     bool nf5, small_m;
@@ -1335,6 +1506,20 @@ bool uv_linear_fold_consumer_ok(long M, int N, int K, bool geglu) {
 
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+    if (p.geglu == 2) {                  // weights in the X-resident kernel's row order (geglu_xres_kernel)
+        auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        UV_REQUIRE(mode == 0 && p.K == XR_K && p.N % XR_BN == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 && al16(p.X) && al16(p.W) && al16(p.Y) && al16(p.bias) &&
+                   !p.R && !p.rowbias && !p.bias2 && !p.stats_out && !p.act && !p.gate && !p.gn_out && (long)p.M * p.ldx < (1L << 31) &&
+                   (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0 && !p.bias)),
+                   "geglu (X-resident order): needs K = 320, N %% 256 == 0, 16-byte aligned rows, no residual / second bias (M=%d N=%d K=%d)", p.M, p.N, p.K);
+        uv_prof_begin(UV_CLS_GEMM_BIG, 2.0 * p.M * (double)p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.N / 2)), stream);
+        const dim3 grid((p.M + XR_BM - 1) / XR_BM);
+        if (p.ln_stats) hipLaunchKernelGGL((geglu_xres_kernel<2>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((geglu_xres_kernel<0>), grid, dim3(512), 0, stream, p);
+        uv_prof_end(stream);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
     const bool lnf = p.ln_stats || p.stats_out;
     UV_REQUIRE(p.K % 8 == 0, "gemm: K=%d must be a multiple of 8", p.K);
     UV_REQUIRE(!(p.act || p.gate) || (!p.geglu && !lnf && mode == 0), "gemm: the activation / gate epilogue is for plain linears (no GEGLU, LayerNorm fold, conv)");

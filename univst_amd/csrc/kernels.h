@@ -25,7 +25,7 @@ struct GemmParams {
     const half_t* R = nullptr;         // residual [M, ldr]
     long ldr = 0;
     const half_t* bias2 = nullptr;     // second bias added after fp16 rounding (attn_temporal bias)
-    int geglu = 0;                     // W rows interleaved [16 x | 16 gate]; writes N/2 columns x*gelu(gate)
+    int geglu = 0;                     // 1: W rows interleaved [16 x | 16 gate]; 2: the X-resident kernel's order (K = 320; uv_launch_geglu_xres_permute); writes N/2 columns x*gelu(gate)
     // MM-DiT epilogues (SD3 path; not with geglu / the LayerNorm fold): Y = R + gate[m / rows_per_gate] (.) act(acc + bias + rowbias)
     int act = 0;                       // 1: GELU(tanh)  (FeedForward activation_fn="gelu-approximate")
     const half_t* gate = nullptr;      // [M / rows_per_gate] rows of N gate values, ld_gate halfs apart (a chunk of the adaLN linear's output)
@@ -89,6 +89,9 @@ bool uv_linear_takes_big_direct(long M, int N, int K, long ldx = 0);
 // or the 128-wide path when that runs the problem without split-K; the GEGLU consumer is 256x320 only)
 bool uv_linear_fold_producer_ok(long M, int N, int K);
 bool uv_linear_fold_consumer_ok(long M, int N, int K, bool geglu);
+// GEGLU projection with K = 320 on the X-resident kernel (GemmParams::geglu = 2): shape test and the weight / bias row permutation it needs
+bool uv_geglu_xres_ok(int N, int K, long M = 0);
+int uv_launch_geglu_xres_permute(const half_t* in, half_t* out, int rows, int cols, hipStream_t stream);
 constexpr size_t UV_SPLITK_WS_BYTES = 128u << 20;  // fp32 partials [splits][M][N]: 8 splits of the 8x8-level convs (3072 x 1280)
 int uv_launch_linear_small(const half_t* x, const half_t* W, const half_t* b, half_t* y, int M, int N, int K, int silu_in,
                            hipStream_t stream);

@@ -439,16 +439,27 @@ int UNet::finalize(hipStream_t s) {
             int rc = derive_alloc(k + "#geglu", {rows, cols}, &d);
             if (rc) return rc;
             hipLaunchKernelGGL(geglu_interleave_kernel, dim3(nb((long)rows * cols)), dim3(256), 0, s, t.ptr, d, rows, cols);
+            // K = 320 (the 64x64 level): a second copy in the row order of the X-resident kernel (gemm.hip geglu_xres_kernel)
+            const int kdim = ends(k, ".weight") ? cols : (int)weights[k.substr(0, k.size() - strlen("bias")) + "weight"].shape[1];
+            if (uv_geglu_xres_ok(rows, kdim)) {
+                half_t* dx;
+                rc = derive_alloc(k + "#xres", {rows, cols}, &dx);
+                if (rc) return rc;
+                rc = uv_launch_geglu_xres_permute(t.ptr, dx, rows, cols, s);
+                if (rc) return rc;
+            }
         }
     }
     // LayerNorm-folded copies of the three linears that follow norm1 / norm2 / norm3 of every transformer block
     for (const std::string& k : keys) {
         if (!ends(k, ".transformer_blocks.0.norm1.weight")) continue;
         const std::string b = k.substr(0, k.size() - strlen(".norm1.weight"));
-        struct { const char* norm; std::string w; std::string bias; } jobs[3] = {
+        struct FoldJob { const char* norm; std::string w; std::string bias; };
+        std::vector<FoldJob> jobs = {
             {".norm1", b + (find(b + ".attn1.qkv#fused#qs") ? ".attn1.qkv#fused#qs" : ".attn1.qkv#fused"), ""},
             {".norm2", b + (find(b + ".attn2.to_q.weight#qs") ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight"), ""},
             {".norm3", b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu"}};
+        if (find(b + ".ff.net.0.proj.weight#xres")) jobs.push_back({".norm3", b + ".ff.net.0.proj.weight#xres", b + ".ff.net.0.proj.bias#xres"});
         for (auto& j : jobs) {
             const WTensor *w = find(j.w), *gm = find(b + j.norm + ".weight"), *bt = find(b + j.norm + ".bias");
             const WTensor* bi = j.bias.empty() ? nullptr : find(j.bias);
@@ -879,7 +890,8 @@ struct Fwd {
         // norm3 with the statistics from a 128-wide producer: UNIVST_LN_FOLD_SMALL=1 leaves it a LayerNorm launch (A/B: emulated rank of 8,
         // F = 16: 12.83 ms per step without the 128-wide fold, 12.81 with norm1 / norm2 only, 12.70 with all three)
         static const int fold_small = getenv("UNIVST_LN_FOLD_SMALL") ? atoi(getenv("UNIVST_LN_FOLD_SMALL")) : 2;
-        const bool fold3 = fold && u.ln_fold > 1 && uv_linear_fold_consumer_ok(rows, 8 * C, C, true) && (fold_small > 1 || uv_linear_takes_big_direct(rows, C, C));
+        const bool xres3 = u.find(b + ".ff.net.0.proj.weight#xres") != nullptr && uv_geglu_xres_ok(8 * C, C, rows);
+        const bool fold3 = fold && u.ln_fold > 1 && (xres3 || uv_linear_fold_consumer_ok(rows, 8 * C, C, true)) && (fold_small > 1 || uv_linear_takes_big_direct(rows, C, C));
         float* lnst = fold ? (float*)alloc(rows * (C / 160) * 4) : nullptr;      // [rows][C/160][2] fp32
         if (fold && !lnst) return UV_ERR_STATE;
         RUN(linear(t0, C, rows, C, p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight"), p + ".proj_in.bias", C, h, C,
@@ -974,11 +986,15 @@ struct Fwd {
             if (nbands == 1) free(h2);
             if (!mid && !(mid = alloc(brows * 4 * C))) return UV_ERR_STATE;
             // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
+            // (K = 320: the X-resident kernel and its weight order, any row count)
+            const bool xres = u.find(b + ".ff.net.0.proj.weight#xres") != nullptr && uv_geglu_xres_ok(8 * C, C, brows);
+            const std::string wff = b + (xres ? ".ff.net.0.proj.weight#xres" : ".ff.net.0.proj.weight#geglu");
+            const std::string bff = b + (xres ? ".ff.net.0.proj.bias#xres" : ".ff.net.0.proj.bias#geglu");
             if (!fold3) {
                 RUN(uv_launch_layernorm(h3 + o, C, t0 + o, C, gm3, bt3, brows, C, 1e-5f, s));
-                RUN(linear(t0 + o, C, brows, C, b + ".ff.net.0.proj.weight#geglu", b + ".ff.net.0.proj.bias#geglu", 8 * C, mid, 4 * C, nullptr, 0, nullptr, 1));
+                RUN(linear(t0 + o, C, brows, C, wff, bff, 8 * C, mid, 4 * C, nullptr, 0, nullptr, xres ? 2 : 1));
             } else {
-                RUN(linear(h3 + o, C, brows, C, b + ".ff.net.0.proj.weight#geglu#ln", "", 8 * C, mid, 4 * C, nullptr, 0, nullptr, 1, nullptr, lb));
+                RUN(linear(h3 + o, C, brows, C, wff + "#ln", "", 8 * C, mid, 4 * C, nullptr, 0, nullptr, xres ? 2 : 1, nullptr, lb));
             }
             if (nbands == 1 && lnst) free(lnst);
             if (!h4 && !(h4 = alloc(rows * C))) return UV_ERR_STATE;
