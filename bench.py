@@ -582,7 +582,7 @@ def main():
             pm = json.load(open(os.path.join(ROOT, "profiles", cands[-1])))["kernels"]
             import re
             # class label -> the kernel symbols it times (template arguments as rocprofv3 prints them; tools/summarize_profiles.py uses the same map)
-            pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
+            pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,|geglu_xres_kernel<", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
                    "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0[,>]"}.get(dom, re.escape(dom.replace(" ", "")))
             hit = [v for k, v in pm.items() if re.search(pat, k.replace(" ", ""))]
             if hit and world == 1:      # a class may span several symbols (the 256- and 192-row tile): launch-weighted mean

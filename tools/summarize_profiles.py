@@ -27,7 +27,7 @@ def per_kernel(pattern, counter):
 fe, wr = per_kernel("fetch/**/*counter_collection.csv", "FETCH_SIZE"), per_kernel("write/**/*counter_collection.csv", "WRITE_SIZE")
 kern = {}
 for k in fe:
-    if not any(t in k for t in ("gemm", "attn", "groupnorm", "gn_", "layernorm", "adain", "conv")):
+    if not any(t in k for t in ("gemm", "geglu", "attn", "groupnorm", "gn_", "layernorm", "adain", "conv")):
         continue
     f_kb = fe[k][0] / max(fe[k][1], 1)
     w_kb = wr[k][0] / max(wr[k][1], 1) if k in wr else 0.0
@@ -46,7 +46,7 @@ try:
     dom = b["roofline"]["kernel"]
     import re
     # bench.py class label -> the kernel symbols it times (template arguments as rocprofv3 prints them)
-    pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
+    pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,|geglu_xres_kernel<", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
            "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0[,>]", "attn_kernel_occ3<96,5,2>": r"attn_kernel_occ3<96,5,2>"}.get(dom, re.escape(dom.replace(" ", "")))
     rows = [r for r in csv.DictReader(open(ks)) if re.search(pat, r["Name"].replace(" ", ""))]
     tot_ns = sum(float(r["TotalDurationNs"]) for r in rows); calls = sum(int(r["Calls"]) for r in rows)

@@ -143,7 +143,7 @@ int uv_launch_window_store(const float* acc, float weight, uint8_t* dst, long n,
 // one class per kernel SYMBOL that matters, so bench.py's average launch duration is comparable with the
 // rocprofv3 --stats row of the same name
 enum {
-    UV_CLS_GEMM_BIG = 0,    // gemm_big_kernel<0>
+    UV_CLS_GEMM_BIG = 0,    // gemm_big_kernel<0> and geglu_xres_kernel (the K = 320 GEGLU projection)
     UV_CLS_CONV_BIG = 1,    // gemm_big_kernel<1>
     UV_CLS_GEMM = 2,        // gemm_kernel<*,0,...>
     UV_CLS_CONV = 3,        // gemm_kernel<*,1,...>
