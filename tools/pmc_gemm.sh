@@ -17,7 +17,7 @@ import csv, sys, glob, collections
 d = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "gemm_" in r["Kernel_Name"] or "conv_patch" in r["Kernel_Name"]:
+        if "gemm_" in r["Kernel_Name"] or "conv_patch" in r["Kernel_Name"] or "geglu_xres" in r["Kernel_Name"]:
             d[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(d):
     print(f"{k:36s} {sum(d[k]) / len(d[k]):16.0f}  (n={len(d[k])})")
