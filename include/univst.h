@@ -120,7 +120,9 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
  *             (to_out -> attn2 -> to_out -> GEGLU feed-forward, attention.py:316-329) runs band by band over whole frames so that a band's
  *             intermediates stay in the 256 MB Infinity Cache: 0 = auto (bands of >= 65 536 rows), n = n bands.  Same results up to fp32
  *             summation order (a band may take another tile than the full tensor).  An
- *             experiment kept as a switch: -13 % on the isolated chain (tools/bench_mall_bands.py), +0.4 ms per step in the graph. */
+ *             experiment kept as a switch: -13 % on the isolated chain (tools/bench_mall_bands.py), +0.4 ms per step in the graph.
+ *   "attn2_fused" (default 1, env UNIVST_ATTN2_FUSED=0 disables it library-wide): the text cross-attention of a transformer block (attention.py:321-327)
+ *             as one launch (univst_attn2_fused) where the level's shape is served, instead of q projection + attention + out projection. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
@@ -151,6 +153,25 @@ int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* b
 int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias, const void* residual, int64_t ldr,
                      void* Y, int64_t ldy, int M, int N, int K, int geglu, const float* ln_stats, float ln_eps,
                      const float* ln_wsum, const float* ln_bias, float* stats_out, void* stream);
+/* The text cross-attention of a transformer block as ONE launch (attention.py:321-327: norm2 -> attn2 -> + hidden_states; the attention itself
+ * is diffusers' Attention with 77 text keys, third-party):
+ *     Y = to_out( softmax( (LN(X) Wq^T)(text Wk^T)^T / sqrt(d) ) (text Wv^T) ) + bias_o + residual
+ * replacing univst_linear_ln (q) + univst_attention (one 77-key source) + univst_linear (out + residual) and the HBM round trips of Q and O.
+ *   X [M, ldx] input rows; with ln_stats (fp32 [M][C/160][2], written by the linear that produced X: univst_linear_ln's stats_out) X holds the
+ *       RAW rows and Wq_frag is made from fp16(gamma[k] * Wq[n][k]), ln_wsum / ln_bias as in univst_linear_ln; else X is already normalised.
+ *   Wq_frag, Wo_frag: the [C, C] weights in MFMA operand order (univst_frag_pack); q_prescaled != 0: Wq already carries log2(e)/sqrt(d).
+ *   kv [B*T, 2C]: K | V rows of the text tokens of every branch (T <= 80 keys); rows [b*rows_per_branch, (b+1)*rows_per_branch) of X attend to branch b.
+ *   stats_out (may be NULL): fp32 [M][C/160][2] row statistics of Y for a following folded LayerNorm.
+ *   workspace: univst_attn2_fused_workspace_bytes(B, heads, head_dim) (K / V of every (branch, head) in operand order).
+ * Served: C = 320 with 8 heads (the 64x64 level of SD-v1.x), rows_per_branch % 64 == 0; else UNIVST_ERR_ARG. */
+int64_t univst_attn2_fused_workspace_bytes(int B, int heads, int head_dim);
+int univst_attn2_fused(const void* X, int64_t ldx, const float* ln_stats, float ln_eps, const float* ln_wsum, const float* ln_bias,
+                       const void* Wq_frag, int q_prescaled, const void* kv, int B, int T, int64_t rows_per_branch, const void* Wo_frag,
+                       const void* bias_o, const void* residual, int64_t ldr, void* Y, int64_t ldy, int64_t M, int C, int heads,
+                       float* stats_out, void* workspace, void* stream);
+/* W [N][K] (N % 16 == 0, K % 32 == 0) -> the order in which v_mfma_f32_16x16x32_f16 takes it as its A operand: [N/16][K/32][64 lanes][8 halfs],
+ * lane (l15, g) = W[nf*16 + l15][ks*32 + g*8 .. +8] — one contiguous 1 KB load per fragment for kernels that read weights straight into registers. */
+int univst_frag_pack(const void* W, void* out, int N, int K, void* stream);
 /* NHWC implicit-GEMM conv: taps 9 (3x3, pad 1) or 1; optional second source (channel concat), fused nearest x2
  * upsample of the input, stride 1/2.  W is [Cout][taps][C1+C2].  Replaces resnet.py:57-80,145,226. */
 int univst_conv_nhwc(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, int stride,
@@ -305,10 +326,11 @@ int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n,
 
 /* ------------------------------------------------------------------ per-kernel-class HIP-event timing (bench.py roofline leg)
  * classes (one per kernel symbol): 0 gemm_big<0>, 1 gemm_big<1> (conv), 2 gemm_kernel<*,0> (linear), 3 gemm_kernel<*,1>
- * (conv), 4 attention d=40, 5 attention d=80, 6 other attention, 7 groupnorm, 8 layernorm, 9 adain shift.
+ * (conv), 4 attention d=40, 5 attention d=80, 6 other attention, 7 groupnorm, 8 layernorm, 9 adain shift, 10 text attention,
+ * 11 conv_patch_kernel (LDS-patch 3x3 convs), 12 attn2_fused_kernel.
  * While enabled every launch of these classes is bracketed by hipEvents on its stream; collect() waits for
  * them and returns per class: summed ms, launch count, algorithmic flops and algorithmic bytes. */
-#define UNIVST_PROFILE_CLASSES 10
+#define UNIVST_PROFILE_CLASSES 13
 int univst_profile_enable(int on);
 int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int nclasses);
 

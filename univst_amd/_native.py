@@ -65,6 +65,9 @@ SIGNATURES = {
     "univst_linear": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "univst_linear_ln": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "univst_geglu_xres_permute": (_I, [_P, _P, _I, _I, _P]),
+    "univst_frag_pack": (_I, [_P, _P, _I, _I, _P]),
+    "univst_attn2_fused_workspace_bytes": (_L, [_I, _I, _I]),
+    "univst_attn2_fused": (_I, [_P, _L, _P, _F, _P, _P, _P, _I, _P, _I, _I, _L, _P, _P, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv3x3_patch": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
@@ -180,6 +183,35 @@ def geglu_xres_permute(w):
     w = w.contiguous()
     out = torch.empty_like(w)
     check(load().univst_geglu_xres_permute(ptr(w), ptr(out), w.shape[0], 1 if w.dim() == 1 else w.shape[1], stream_ptr()), "geglu_xres_permute")
+    return out
+
+
+def frag_pack(w):
+    """[N, K] weight -> MFMA A-operand order [N/16][K/32][64][8] (same numel)."""
+    _f16(w)
+    w = w.contiguous()
+    out = torch.empty_like(w)
+    check(load().univst_frag_pack(ptr(w), ptr(out), w.shape[0], w.shape[1], stream_ptr()), "frag_pack")
+    return out
+
+
+def attn2_fused(x, wq_frag, kv, wo_frag, bias_o, rows_per_branch, heads, residual=None, ln=None, q_prescaled=False, stats_out=None, out=None,
+                eps=1e-5):
+    """The text cross-attention of a transformer block in one launch: x [M, C] (raw rows when ``ln = (stats [M, C/160, 2], wsum [C], lnb [C])``
+    folds the LayerNorm), kv [B*T, 2C] text K | V rows -> to_out(attention) + bias + residual (default: x)."""
+    _f16(x), _f16(wq_frag), _f16(kv), _f16(wo_frag)
+    M, C_ = x.shape
+    B = -(-M // rows_per_branch)
+    T = kv.shape[0] // B
+    residual = x if residual is None else residual
+    out = torch.empty(M, C_, device=x.device, dtype=torch.float16) if out is None else out
+    st, ws, lb = ln if ln is not None else (None, None, None)
+    for t in (st, ws, lb, stats_out):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    wsb = torch.empty(max(int(load().univst_attn2_fused_workspace_bytes(B, heads, C_ // heads)), 16), device=x.device, dtype=torch.uint8)
+    check(load().univst_attn2_fused(ptr(x), x.stride(0), ptr(st), eps, ptr(ws), ptr(lb), ptr(wq_frag), int(q_prescaled), ptr(kv), B, T,
+                                    rows_per_branch, ptr(wo_frag), ptr(bias_o), ptr(residual), residual.stride(0), ptr(out), out.stride(0), M, C_,
+                                    heads, ptr(stats_out), ptr(wsb), stream_ptr()), "attn2_fused")
     return out
 
 
@@ -488,7 +520,7 @@ def debug_tr16():
 
 PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>", "gemm_kernel<*,1>", "attn_pp40_kernel<true>",
                    "attn_kernel_occ3<96,5,2>", "attn_kernel<other>", "groupnorm", "layernorm", "adain_shift", "attn_kernel<text>",
-                   "conv_patch_kernel")
+                   "conv_patch_kernel", "attn2_fused_kernel")
 
 
 def profile_enable(on: bool):

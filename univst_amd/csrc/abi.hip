@@ -1,4 +1,5 @@
 // extern "C" surface of libunivst_hip.so (include/univst.h).  Thin argument checking + dispatch.
+#include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
 #include <string.h>
@@ -56,6 +57,10 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value) {
     if (!strcmp(name, "ln_fold")) {
         UV_REQUIRE(value >= 0 && value <= 2, "unet_set_option: ln_fold is 0, 1 or 2");
         h->impl.ln_fold = value;
+        return UV_OK;
+    }
+    if (!strcmp(name, "attn2_fused")) {
+        h->impl.attn2_fused = value != 0;
         return UV_OK;
     }
     if (!strcmp(name, "gn_producer")) {
@@ -133,6 +138,35 @@ int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* b
 int univst_geglu_xres_permute(const void* in, void* out, int rows, int cols, void* s) {
     UV_REQUIRE(in && out, "geglu_xres_permute: null argument");
     return uv_launch_geglu_xres_permute(H(in), HM(out), rows, cols, S(s));
+}
+int univst_frag_pack(const void* W, void* out, int N, int K, void* s) {
+    UV_REQUIRE(W && out, "frag_pack: null argument");
+    return uv_launch_frag_pack(H(W), HM(out), N, K, S(s));
+}
+int64_t univst_attn2_fused_workspace_bytes(int B, int heads, int head_dim) { return uv_attn2_kvf_halfs(B, heads, head_dim) * (int64_t)sizeof(half_t); }
+int univst_attn2_fused(const void* X, int64_t ldx, const float* ln_stats, float ln_eps, const float* ln_wsum, const float* ln_bias, const void* Wq_frag,
+                       int q_prescaled, const void* kv, int B, int T, int64_t rows_per_branch, const void* Wo_frag, const void* bias_o,
+                       const void* residual, int64_t ldr, void* Y, int64_t ldy, int64_t M, int C, int heads, float* stats_out, void* workspace,
+                       void* s) {
+    UV_REQUIRE(X && Wq_frag && kv && Wo_frag && residual && Y && workspace, "attn2_fused: null argument");
+    UV_REQUIRE(B >= 1 && M >= 1 && M <= (int64_t)B * rows_per_branch && M < (1LL << 31) && C % 160 == 0 && heads > 0 && C % heads == 0,
+               "attn2_fused: M=%lld rows exceed B=%d branches of %lld rows (or bad C / heads)", (long long)M, B, (long long)rows_per_branch);
+    UV_REQUIRE(!ln_stats || (ln_wsum && ln_bias), "attn2_fused: a folded LayerNorm needs ln_wsum and ln_bias");
+    UV_REQUIRE(uv_attn2_fused_ok(C, heads, (int)rows_per_branch, T), "attn2_fused: C=%d heads=%d rows_per_branch=%lld keys=%d is not a shape this kernel serves "
+               "(C = 320, 8 heads, rows per branch a multiple of 64, <= 80 keys)", C, heads, (long long)rows_per_branch, T);
+    int rc = uv_launch_kv_frag_pack(H(kv), HM(workspace), B, T, C, heads, S(s));
+    if (rc) return rc;
+    Attn2Params p;
+    p.X = H(X); p.ldx = ldx; p.M = (int)M;
+    p.ln_stats = ln_stats; p.ln_slots = C / 160; p.ln_eps = ln_eps; p.ln_wsum = ln_wsum; p.ln_bias = ln_bias;
+    p.Wq_f = H(Wq_frag); p.kvf = H(workspace);
+    p.rows_per_branch = (int)rows_per_branch; p.heads = heads; p.Nkv = T;
+    p.q_prescaled = q_prescaled; p.scale_log2e = 1.4426950408889634f / sqrtf((float)(C / heads));
+    p.Wo_f = H(Wo_frag); p.bias_o = H(bias_o);
+    p.R = H(residual); p.ldr = ldr;
+    p.Y = HM(Y); p.ldy = ldy;
+    p.stats_out = stats_out;
+    return uv_launch_attn2_fused(p, C, S(s));
 }
 int univst_linear_ln(const void* X, int64_t ldx, const void* W, const void* bias, const void* R, int64_t ldr, void* Y, int64_t ldy,
                      int M, int N, int K, int geglu, const float* ln_stats, float ln_eps, const float* ln_wsum, const float* ln_bias,

@@ -83,6 +83,38 @@ struct AttnParams {
     int Nkv_x = 0;
 };
 
+// The text cross-attention of a transformer block as ONE launch (fused.hip: attention.py:321-327 = norm2 -> attn2 -> + residual)
+struct Attn2Params {
+    const half_t* X = nullptr;          // [M, ldx] input rows: RAW rows when ln_stats is set (LayerNorm folded), else already normalised
+    long ldx = 0;
+    int M = 0;
+    const float* ln_stats = nullptr;    // [M][ln_slots][2] (sum, sumsq) per 160-column slot from the producer of X (GemmParams::stats_out), or null
+    int ln_slots = 0;
+    float ln_eps = 1e-5f;
+    const float* ln_wsum = nullptr;     // [C] fp32 (see GemmParams)
+    const float* ln_bias = nullptr;     // [C] fp32
+    const half_t* Wq_f = nullptr;       // to_q weight (gamma-folded when ln_stats) in MFMA operand order (uv_launch_frag_pack)
+    const half_t* kvf = nullptr;        // text K | V of every (branch, head) in operand order (uv_launch_kv_frag_pack)
+    int rows_per_branch = 0, heads = 0, Nkv = 0;
+    int q_prescaled = 0;                // the to_q weight carries log2(e)/sqrt(d)
+    float scale_log2e = 0.f;
+    const half_t* Wo_f = nullptr;       // to_out weight in operand order
+    const half_t* bias_o = nullptr;     // [C] or null
+    const half_t* R = nullptr;          // residual rows [M, ldr]
+    long ldr = 0;
+    half_t* Y = nullptr;
+    long ldy = 0;
+    float* stats_out = nullptr;         // [M][C/160][2] row statistics of Y for a following folded LayerNorm, or null
+#ifdef UV_A2_TRACE
+    long long* trace = nullptr;         // tools/probes/attn2_probe.hip: [blocks][4 waves][8] cycle counter at the phase boundaries
+#endif
+};
+bool uv_attn2_fused_ok(int C, int heads, int rows_per_branch, int Nkv);
+long uv_attn2_kvf_halfs(int B, int heads, int D);
+int uv_launch_frag_pack(const half_t* W, half_t* out, int N, int K, hipStream_t s);
+int uv_launch_kv_frag_pack(const half_t* kv, half_t* out, int B, int T, int C, int heads, hipStream_t s);
+int uv_launch_attn2_fused(const Attn2Params& p, int C, hipStream_t s);
+
 int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream);
 bool uv_linear_takes_big_direct(long M, int N, int K, long ldx = 0);
 // LayerNorm fold around a plain linear: may it emit the row statistics of its output / apply those of its input?  (256x320 direct path,
@@ -155,7 +187,8 @@ enum {
     UV_CLS_ADAIN = 9,
     UV_CLS_ATTN_TEXT = 10,  // the 77-key text cross-attention launches (any head_dim): reported apart from the self-attention
     UV_CLS_CONV_PATCH = 11, // conv_patch_kernel<*>: 3x3 / stride-1 convs from an input patch kept in LDS
-    UV_NCLS = 12
+    UV_CLS_ATTN2_FUSED = 12, // attn2_fused_kernel: q projection + 77-key text attention + out projection + residual in one launch
+    UV_NCLS = 13
 };
 void uv_prof_enable(int on);
 bool uv_prof_on();

@@ -475,6 +475,23 @@ int UNet::finalize(hipStream_t s) {
                                (float*)ws, (float*)lb, (int)K);
         }
     }
+    // the fused text cross-attention (fused.hip, the 64x64 level of SD-v1.x): to_q (plain and LayerNorm-folded) and to_out in MFMA operand order
+    for (const std::string& k : keys) {
+        if (!ends(k, ".attn2.to_out.0.weight")) continue;
+        const std::string b = k.substr(0, k.size() - strlen(".attn2.to_out.0.weight"));
+        const WTensor& t = weights[k];
+        if (t.shape.size() != 2 || t.shape[0] != t.shape[1] || !uv_attn2_fused_ok((int)t.shape[0], cfg.attention_heads[level_of(k)], 64, 77)) continue;
+        const std::string wq = b + (find(b + ".attn2.to_q.weight#qs") ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight");
+        for (const std::string& src : {k, wq, wq + "#ln"}) {
+            const WTensor* w = find(src);
+            if (!w) continue;
+            half_t* d;
+            int rc = derive_alloc(src + "#frag", {w->shape[0], w->shape[1]}, &d);
+            if (rc) return rc;
+            rc = uv_launch_frag_pack(w->ptr, d, (int)w->shape[0], (int)w->shape[1], s);
+            if (rc) return rc;
+        }
+    }
     {   // all resnets' time_emb_proj stacked into one [sum Cout, 4*C0] matrix: one projection launch per forward instead of 22
         std::vector<std::string> tk;
         for (const std::string& k : keys)
@@ -968,8 +985,35 @@ struct Fwd {
             float* lb = lnst ? lnst + r0 * (C / 160) * 2 : nullptr;
             RUN(linear(t0 + o, C, brows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2 + o, C, h + o, C, nullptr, 0, lb));
             if (nbands == 1) free(h);
-            if (!q2 && !(q2 = alloc(brows * C))) return UV_ERR_STATE;
             // ---- attn2 (text)
+            // ONE launch where the shape allows (round 5, fused.hip): q projection (LayerNorm folded), the 77-key attention of the wave's two
+            // heads and the out projection + residual share one 64-row tile in LDS — Q and O never reach HBM
+            const std::string wqf = wq2 + (fold ? "#ln#frag" : "#frag"), wof = b + ".attn2.to_out.0.weight#frag";
+            if (nbands == 1 && u.attn2_fused && uv_attn2_fused_ok(C, heads, F * N, text_len) && u.find(wqf) && u.find(wof)) {
+                half_t* kvf = alloc(uv_attn2_kvf_halfs(B, heads, d));
+                if (!kvf || !(h3 = alloc(rows * C))) return UV_ERR_STATE;
+                RUN(uv_launch_kv_frag_pack(kv, kvf, B, text_len, C, heads, s));
+                if (!fold) RUN(uv_launch_layernorm(h2, C, t0, C, gm2, bt2, rows, C, 1e-5f, s));
+                Attn2Params a2;
+                a2.X = fold ? h2 : t0; a2.ldx = C; a2.M = (int)rows;
+                if (fold) {
+                    a2.ln_stats = lb; a2.ln_slots = C / 160; a2.ln_eps = 1e-5f;
+                    a2.ln_wsum = (const float*)W(wq2 + "#ln.wsum"); a2.ln_bias = (const float*)W(wq2 + "#ln.bias");
+                    if (!a2.ln_wsum || !a2.ln_bias) return u.missing_error();
+                }
+                a2.Wq_f = W(wqf); a2.kvf = kvf;
+                a2.rows_per_branch = F * N; a2.heads = heads; a2.Nkv = text_len;
+                a2.q_prescaled = qs2; a2.scale_log2e = ap.scale_log2e;
+                a2.Wo_f = W(wof); a2.bias_o = W(b + ".attn2.to_out.0.bias");
+                a2.R = h2; a2.ldr = C; a2.Y = h3; a2.ldy = C;
+                a2.stats_out = fold3 ? lb : nullptr;
+                if (!a2.bias_o) return u.missing_error();
+                RUN(uv_launch_attn2_fused(a2, C, s));
+                free(kvf);
+                free(kv);
+                free(h2);
+            } else {
+            if (!q2 && !(q2 = alloc(brows * C))) return UV_ERR_STATE;
             if (!fold) RUN(uv_launch_layernorm(h2 + o, C, t0 + o, C, gm2, bt2, brows, C, 1e-5f, s));
             if (fold) RUN(linear(h2 + o, C, brows, C, wq2 + "#ln", "", C, q2, C, nullptr, 0, nullptr, 0, nullptr, lb));
             else RUN(linear(t0 + o, C, brows, C, wq2, "", C, q2, C));
@@ -984,6 +1028,7 @@ struct Fwd {
             if (!h3 && !(h3 = alloc(rows * C))) return UV_ERR_STATE;
             RUN(linear(t0 + o, C, brows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3 + o, C, h2 + o, C, nullptr, 0, fold3 ? lb : nullptr));
             if (nbands == 1) free(h2);
+            }
             if (!mid && !(mid = alloc(brows * 4 * C))) return UV_ERR_STATE;
             // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
             // (K = 320: the X-resident kernel and its weight order, any row count)
