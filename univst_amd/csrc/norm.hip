@@ -398,7 +398,7 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     // producer statistics are usable when every source has them and the groups are whole runs of 10-channel sub-groups
     if (pre_part && !((!s2 || pre_part2) && (C / G) % 10 == 0 && C1 % 10 == 0 && C2 % 10 == 0 && rows_per_stat % 16 == 0)) pre_part = nullptr;
     if (!pre_part && (C / G) % 2 == 0 && C1 % 2 == 0 && rows * C * 2 <= small_bytes && (long)S * G >= 48) {
-        uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
+        uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 4.0 * (double)rows * C, stream);      // one read from memory (the block's second read comes out of L2) + one write
         if (!sharded_stats) {
             hipLaunchKernelGGL((gn_small_kernel<0>), dim3(G, S), dim3(256), 0, stream, s1, s2, C1, C2, rows_per_stat, G, eps, gamma, beta, silu, out, (float*)nullptr);
             uv_prof_end(stream);
@@ -438,7 +438,8 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     if (nchunk < 1) nchunk = 1;
     const int rpc = (rows_per_stat + nchunk - 1) / nchunk;
     nchunk = (rows_per_stat + rpc - 1) / rpc;
-    uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 6.0 * (double)rows * C, stream);
+    // what the launches below move: the apply pass reads and writes the tensor; the statistics pass reads it once more unless the producers left them
+    uv_prof_begin(UV_CLS_GROUPNORM, 0.0, (pre_part ? 4.0 : 6.0) * (double)rows * C, stream);
     size_t lds1 = (size_t)3 * TR * C * sizeof(float);
     UV_REQUIRE(lds1 <= 160 * 1024, "groupnorm: LDS %zu too large", lds1);
     const float* chunk_part = part;
