@@ -18,6 +18,8 @@ masks blended on steps 0..45).  --workload selects the other driver-timed lines 
   transfer_nomask   the same loop without masks
   inversion         BASELINE config 2: the single-branch DDIM inversion loop (one step = one single-branch UNet call + next_step)
   inversion_pair    the content + style inversions of one job as one batch-2 trajectory (value = frames of BOTH clips / s)
+  vae_decode        the final decode of the clip (and each decode of the pixel smoother leg): the SVD temporal VAE decoder on the native library,
+                    16 x 4 x 64 x 64 latents -> 16 x 3 x 512 x 512 frames (random-init weights of that architecture)
   maskprop          point-matching mask propagation of a 16-frame clip (64x64x640 features, 256 classes, 512^2 masks); HBM-bound
   warp              one sliding-window smoothing pass over 16 x 512^2 frames (58 occlusion + remap + blend warps in 16 launches, one per key frame); HBM-bound
 """
@@ -50,7 +52,7 @@ def parse():
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
-    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "inversion_pair", "maskprop", "warp", "sd3_transfer"])
+    ap.add_argument("--workload", default="transfer", choices=["transfer", "transfer_nomask", "inversion", "inversion_pair", "maskprop", "warp", "sd3_transfer", "vae_decode"])
     ap.add_argument("--model", default="sd15", choices=["sd15", "sd21"], help="UNet configuration: SD-v1.5 (headline) or the SD-v2.1 layout "
                                                                             "(Linear projections, head_dim 64, 1024-wide text states; SURVEY §8f-3)")
     ap.add_argument("--full-cpu", action="store_true", help="cpu_baseline: time the two representative steps at the full frame count "
@@ -174,6 +176,63 @@ def hbm_roofline(kernel, algorithmic_bytes, ms, launches):
     return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_ms": round(ms / launches, 4),
             "algorithmic_mb_per_launch": round(algorithmic_bytes / launches / 1e6, 2)}
+
+
+def vae_decode_flops(cfg, imgs, F_, h, w):
+    """algorithmic matrix flops of AutoencoderKLTemporalDecoder.decode on imgs frames of h x w latents (2 x MACs of every conv / linear / attention)"""
+    boc, L, lat = cfg["block_out_channels"], cfg["layers_per_block"], cfg["latent_channels"]
+    fl = 0.0
+    px = h * w
+
+    def st(ci, co, px):            # ResnetBlock2D (3x3 convs, 1x1 shortcut) + TemporalResnetBlock (two Conv3d (3,1,1))
+        return 2.0 * px * (9 * ci * co + 9 * co * co + (ci * co if ci != co else 0) + 2 * 3 * co * co)
+    fl += 2.0 * px * 9 * lat * boc[3]
+    fl += L * st(boc[3], boc[3], px) + 2.0 * px * 4 * boc[3] * boc[3] + 4.0 * px * px * boc[3]         # mid block: resnets, q/k/v/out, QK^T + PV
+    ci = boc[3]
+    for b in range(4):
+        co = boc[3 - b]
+        for l in range(L + 1):
+            fl += st(ci, co, px)
+            ci = co
+        if b < 3:
+            px *= 4
+            fl += 2.0 * px * 9 * co * co
+    fl += 2.0 * px * 9 * boc[0] * cfg["out_channels"] + 2.0 * px * 3 * cfg["out_channels"] ** 2
+    return fl * imgs
+
+
+def run_vae_workload(a, dev):
+    """the clip's decode on the native temporal VAE: value = decoded frames / s (one step = one decode of the whole clip)"""
+    from univst_amd import synth, vae
+    F_, h = a.frames, (a.latent or 64)
+    cfg = synth.SVD_VAE_CONFIG
+    v = vae.NativeTemporalVAE(synth.vae_state_dict(cfg, device=dev), cfg, device=dev)
+    z = torch.randn(F_, 4, h, h, device=dev, dtype=torch.float16)
+    for _ in range(max(1, a.warmup)):
+        v.decode(z, num_frames=F_)
+    torch.cuda.synchronize()
+    reps = max(1, a.steps // 5)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(reps):
+        out = v.decode(z, num_frames=F_).sample
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    dev_ms = ev0.elapsed_time(ev1) / reps
+    fl = vae_decode_flops(cfg, F_, F_, h, h)
+    assert torch.isfinite(out.float()).all()
+    return {"metric": f"decoded frames/sec, SVD temporal VAE decoder, {F_}x{h * 8}x{h * 8}", "value": round(F_ / wall, 3), "unit": "frames/s", "n_gpus": 1,
+            "steps": reps, "warmup": max(1, a.warmup), "ms_per_step": round(wall * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"svd_temporal_vae_decode_{F_}x{h * 8}x{h * 8}", "frames": F_, "parallelism": "single",
+                       "weights": "random-init AutoencoderKLTemporalDecoder architecture (128, 256, 512, 512), fp16",
+                       "algorithmic_tflop_per_decode": round(fl / 1e12, 2)},
+            "roofline": {"kernel": "gemm_kernel<4,1> (128 x 128 implicit-GEMM conv tile: the VAE widths 128 / 256 / 512 are not multiples of the 320-column tile)",
+                         "bound": "mfma", "achieved": round(fl / (dev_ms * 1e-3) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(fl / (dev_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4), "traffic": None,
+                         "note": "whole-decode figure (all launches of one decode); off the 50-step loop: the metric's timed region ends before the final decode"}}
 
 
 def run_aux_workload(a, dev):
@@ -435,11 +494,12 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local)
 
-    if a.workload in ("maskprop", "warp", "sd3_transfer"):
-        assert world == 1 or a.workload == "sd3_transfer", "maskprop / warp are sequential over frames: replicas only (DESIGN.md §5)"
+    if a.workload in ("maskprop", "warp", "sd3_transfer", "vae_decode"):
+        assert world == 1 or a.workload == "sd3_transfer", "maskprop / warp / the VAE couple all frames of a clip: replicas only (DESIGN.md §5)"
         from univst_amd import _native
         _native.load()
-        out = run_sd3_workload(a, dev, rank, world, dist) if a.workload == "sd3_transfer" else run_aux_workload(a, dev)
+        out = (run_sd3_workload(a, dev, rank, world, dist) if a.workload == "sd3_transfer" else
+               (run_vae_workload(a, dev) if a.workload == "vae_decode" else run_aux_workload(a, dev)))
         if rank == 0:
             print(json.dumps(out))
         if dist is not None:

@@ -125,6 +125,30 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
  *             as one launch (univst_attn2_fused) where the level's shape is served, instead of q projection + attention + out projection. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 
+/* ------------------------------------------------------------------ temporal VAE handle
+ * The VAE behind the pipeline's decode / encode call sites (stable_diffusion.py:369-394 decode_latents, :793-818 get_images_from_latents,
+ * :820-834 get_latent_image, ddim_inversion.py:28-31,52-55): diffusers' AutoencoderKLTemporalDecoder (the SVD VAE the reference's run_*_sd.py
+ * load, src/sd/run_video_style_transfer_sd.py:36) as one graph of the library's kernels per call.  THIRD-PARTY network, restated from its published
+ * definition with that class's state-dict keys (csrc/vae.hip); parity unpinned by the reference. */
+typedef struct univst_vae univst_vae;
+typedef struct {
+    int in_channels, out_channels, latent_channels;      /* 3, 3, 4 */
+    int block_out_channels[4];                           /* SVD: 128, 256, 512, 512 (multiples of norm_num_groups and of 8) */
+    int layers_per_block;                                /* 2 */
+    int norm_num_groups;                                 /* 32 */
+} univst_vae_cfg;
+int univst_vae_create(const univst_vae_cfg* cfg, univst_vae** out);
+int univst_vae_destroy(univst_vae* h);
+/* key = diffusers state-dict name ("decoder.up_blocks.0.resnets.1.temporal_res_block.conv1.weight", "quant_conv.bias", ...) */
+int univst_vae_load_tensor(univst_vae* h, const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, void* stream);
+int univst_vae_finalize(univst_vae* h, void* stream);
+/* AutoencoderKLTemporalDecoder.decode(z, num_frames).sample: z [imgs, latent, h, w] (imgs = clips x num_frames, already divided by the scaling
+ * factor) -> out [imgs, out_channels, 8h, 8w]; the temporal layers couple the num_frames frames of a clip */
+int univst_vae_decode(univst_vae* h, const void* z, int64_t imgs, int num_frames, int lat_h, int lat_w, void* out, void* stream);
+/* AutoencoderKLTemporalDecoder.encode(x).latent_dist.parameters: x [imgs, in_channels, H, W] in [-1, 1] -> moments [imgs, 2*latent, H/8, W/8]
+ * (mean | logvar; sampling stays with the caller, which owns the RNG) */
+int univst_vae_encode(univst_vae* h, const void* x, int64_t imgs, int H, int W, void* moments, void* stream);
+
 /* ------------------------------------------------------------------ stand-alone operators (also used by tests) */
 /* Y[M,N] = X[M,K] W[N,K]^T + bias + residual; geglu != 0: the diffusers GEGLU projection (FeedForward net[0], attention.py:241) — writes the
  * N/2 columns x * gelu(gate), W / bias rows pre-interleaved: geglu = 1 in blocks of [16 x rows | 16 gate rows] (any K), geglu = 2 in the

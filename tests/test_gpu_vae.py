@@ -1,0 +1,208 @@
+"""GPU parity of the native temporal VAE (csrc/vae.hip through univst_vae_* / univst_amd.vae.NativeTemporalVAE) against the fp32 restatement
+oracle/vae_ref.py on the same fp16-valued random-init weights (reference call sites stable_diffusion.py:369-394, :793-834).
+
+PARITY UNPINNED by the reference: the network is diffusers' AutoencoderKLTemporalDecoder (third-party, absent here); both sides restate its
+published definition.  Tolerance (fp16 storage of every activation across ~70 layers, fp32 accumulation): max error <= 2e-2 of the output scale,
+relative RMS <= 5e-3."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_ref  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from univst_amd import _native
+    _native.load()
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _native
+
+
+def _err(got, ref):
+    got, ref = got.float(), ref.float()
+    return (got - ref).abs().max().item() / ref.abs().max().item(), ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+
+
+SMALL = dict(vae_ref.SVD_VAE_CONFIG, block_out_channels=(64, 128, 128, 128))
+
+
+@pytest.mark.parametrize("cfg,F,hw,clips", [(SMALL, 4, 16, 2),                        # two clips of four frames: the temporal layers must not mix clips
+                                           (SMALL, 16, 8, 1),
+                                           (vae_ref.SVD_VAE_CONFIG, 2, 16, 1)])       # SVD widths (128, 256, 512, 512), 128 x 128 images
+def test_vae_decode_matches_restated_definition(nat, cfg, F, hw, clips):
+    from univst_amd import synth, vae
+    sd = synth.vae_state_dict(cfg, seed=3)
+    v = vae.NativeTemporalVAE(sd, cfg)
+    z = torch.randn(clips * F, 4, hw, hw, generator=torch.Generator().manual_seed(1)).half().cuda()
+    got = v.decode(z, num_frames=F).sample
+    ref = vae_ref.decode({k: t.float() for k, t in sd.items()}, z.float(), F, cfg)
+    assert got.shape == ref.shape == (clips * F, 3, 8 * hw, 8 * hw)
+    mx, rms = _err(got, ref)
+    assert mx < 2e-2 and rms < 5e-3, (mx, rms)
+    # the temporal layers see the clip: decoding the same latents frame by frame must differ (the path is exercised, not bypassed)
+    one = torch.cat([v.decode(z[i:i + 1], num_frames=1).sample for i in range(2)])
+    assert (one.float() - got[:2].float()).abs().max().item() > 10 * mx * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("cfg,H", [(SMALL, 64), (vae_ref.SVD_VAE_CONFIG, 128)])
+def test_vae_encode_moments_and_sampling(nat, cfg, H):
+    from univst_amd import synth, vae
+    sd = synth.vae_state_dict(cfg, seed=5)
+    v = vae.NativeTemporalVAE(sd, cfg)
+    x = (torch.rand(3, 3, H, H, generator=torch.Generator().manual_seed(2)) * 2 - 1).half().cuda()
+    dist = v.encode(x).latent_dist
+    ref = vae_ref.encode_moments({k: t.float() for k, t in sd.items()}, x.float(), cfg)
+    mx, rms = _err(dist.parameters, ref)
+    assert mx < 2e-2 and rms < 5e-3, (mx, rms)
+    # DiagonalGaussianDistribution.sample(): mean + exp(0.5 * clamp(logvar)) * randn, consuming torch's device RNG once
+    torch.manual_seed(11)
+    s = dist.sample()
+    torch.manual_seed(11)
+    n = torch.randn(dist.mean.shape, device="cuda", dtype=torch.float16)
+    assert torch.equal(s, dist.mean + torch.exp(0.5 * dist.logvar.clamp(-30, 20)) * n)
+
+
+def test_vae_behind_the_pipeline_call_sites(nat):
+    """decode_latents / get_images_from_latents / get_latent_image of the pipeline mirror with the native VAE in place of the stock module:
+    same call protocol (num_frames found through the forward signature, scaling factor, uint8 round trip), values vs the restated definition"""
+    from univst_amd import synth, vae
+    from univst_amd.backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline as P
+    sd = synth.vae_state_dict(SMALL, seed=9)
+    v = vae.NativeTemporalVAE(sd, SMALL)
+    pipe = P.__new__(P)
+    import types
+    pipe.vae = v
+    pipe.unet = types.SimpleNamespace(device=torch.device("cuda"))
+    lat = (0.18215 * torch.randn(1, 4, 16, 8, 8, generator=torch.Generator().manual_seed(4))).half().cuda()
+    img = pipe.get_images_from_latents(lat)
+    assert img.shape == (1, 3, 16, 64, 64) and img.dtype == torch.uint8
+    ref = vae_ref.decode({k: t.float() for k, t in sd.items()}, (lat.float() / 0.18215).permute(0, 2, 1, 3, 4).flatten(0, 1), 16, SMALL)
+    ref8 = ((ref / 2 + 0.5).clamp(0, 1) * 255).round().view(1, 16, 3, 64, 64).permute(0, 2, 1, 3, 4)
+    assert (img.float() - ref8).abs().max().item() <= 2          # uint8 levels
+    torch.manual_seed(0)
+    z = pipe.get_latent_image(img)
+    assert z.shape == (1, 4, 16, 8, 8) and z.dtype == torch.float16 and torch.isfinite(z).all()
+
+
+def test_vae_fails_loudly_off_the_gpu(nat):
+    from univst_amd import synth, vae
+    v = vae.NativeTemporalVAE(synth.vae_state_dict(SMALL, seed=1), SMALL)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        v.decode(torch.zeros(1, 4, 8, 8), num_frames=1)
+    bad = synth.vae_state_dict(SMALL, seed=1)
+    del bad["decoder.up_blocks.1.resnets.0.time_mixer.mix_factor"]
+    v2 = vae.NativeTemporalVAE(bad, SMALL)
+    with pytest.raises(RuntimeError, match="mix_factor missing"):
+        v2.decode(torch.zeros(2, 4, 8, 8).half().cuda(), num_frames=2)
+
+
+@pytest.mark.parametrize("lat", [32, 64])
+def test_vae_decode_at_the_baseline_size_16x512x512(nat, lat):
+    """the clip's decode at BASELINE size — 16 x 4 x 64 x 64 latents -> 16 x 3 x 512 x 512 at the SVD widths (128, 256, 512, 512) — against the
+    fp32 restatement run with torch ops ON THE DEVICE on the same fp16-valued weights; numbers go to gpurun_out/parity_vae_baseline_size.json.
+    torch's fp32 convolutions take 4 minutes for the 512 x 512 oracle on this ROCm build, so the routine run checks 16 x 256 x 256 (same graph, same
+    widths, a quarter of the pixels) and the full size runs with UNIVST_TEST_FULL=1 (result of record: profiles/round5_parity_vae_baseline_size.json)."""
+    import json, os, time
+    from univst_amd import synth, vae
+    if lat == 64 and os.environ.get("UNIVST_TEST_FULL", "0") != "1":
+        pytest.skip("16 x 512 x 512 oracle: 4 min of fp32 torch convolutions; UNIVST_TEST_FULL=1 (profiles/round5_parity_vae_baseline_size.json)")
+    cfg = vae_ref.SVD_VAE_CONFIG
+    sd = synth.vae_state_dict(cfg, seed=21)
+    v = vae.NativeTemporalVAE(sd, cfg)
+    z = torch.randn(16, 4, lat, lat, generator=torch.Generator().manual_seed(6)).half().cuda()
+    got = v.decode(z, num_frames=16).sample
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = v.decode(z, num_frames=16).sample
+    torch.cuda.synchronize()
+    t_nat = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ref = vae_ref.decode({k: t.float() for k, t in sd.items()}, z.float(), 16, cfg)
+    torch.cuda.synchronize()
+    t_ref = time.perf_counter() - t0
+    mx, rms = _err(got, ref)
+    # what the pipeline turns it into: uint8 frames (stable_diffusion.py:812-815)
+    g8 = ((got.float() / 2 + 0.5).clamp(0, 1) * 255).round()
+    r8 = ((ref / 2 + 0.5).clamp(0, 1) * 255).round()
+    psnr = 10 * torch.log10(255.0 ** 2 / (g8 - r8).pow(2).mean()).item()
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"clip": f"16x{lat * 8}x{lat * 8}", "max_rel_err": mx, "rel_rms": rms, "uint8_psnr_db": psnr, "native_s": t_nat, "fp32_oracle_on_device_s": t_ref},
+              open(f"gpurun_out/parity_vae_baseline_size{'' if lat == 64 else '_256'}.json", "w"))
+    assert mx < 2e-2 and rms < 5e-3 and psnr > 40.0, (mx, rms, psnr)
+
+
+def test_pixel_smoother_leg_runs_on_the_native_vae():
+    """The pixel smoothing leg of video_style_transfer (stable_diffusion.py:713-759: x0 -> VAE decode -> uint8 -> sliding window -> VAE encode ->
+    return_to_timestep, steps 20..24) with NativeTemporalVAE behind the pipeline's call sites, against the oracle loop that drives the restated VAE
+    (oracle/vae_ref) in fp32.  The posterior's log-variance head is pinned to its clamp (-30) so that latent_dist.sample() is the mean on both sides;
+    uint8 rounding may flip single levels, hence 35 dB on the smoothed steps (the un-smoothed run is > 6 dB further away)."""
+    import types
+    import numpy as np
+    from oracle import pipeline_ref, unet_ref, synth_inputs as si
+    from tests.test_gpu_unet import tiny_unet, dev_oracle, psnr
+    from univst_amd import synth, vae
+    from univst_amd.backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
+    from univst_amd.backbones.video_diffusion_sd import pnp_utils
+    from univst_amd.schedulers import DDIMScheduler
+    unet, sd, cfg = tiny_unet()
+    F_, h, w = 16, 16, 16
+    text = si.text_embedding(cfg["cross_attention_dim"])
+    vsd = synth.vae_state_dict(SMALL, seed=13)
+    vsd["quant_conv.weight"][4:] = 0
+    vsd["quant_conv.bias"][4:] = -40.0
+    nvae = vae.NativeTemporalVAE(vsd, SMALL)
+    vf = {k: t.float() for k, t in vsd.items()}
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, prompt, **kw):
+            n = len(prompt) if isinstance(prompt, list) else 1
+            return types.SimpleNamespace(input_ids=torch.zeros(n, 77, dtype=torch.long), attention_mask=None)
+
+    class Enc(torch.nn.Module):
+        config = types.SimpleNamespace()
+
+        def forward(self, ids, attention_mask=None):
+            return (text.half().cuda().expand(ids.shape[0], -1, -1),)
+
+    pipe = SpatioTemporalStableDiffusionPipeline(vae=nvae, text_encoder=Enc(), tokenizer=Tok(), unet=unet, scheduler=DDIMScheduler())
+    assert pipe.vae_scale_factor == 8
+    ci = [si.content_latent(k, F_, h, w) for k in range(51)]
+    sy = [si.style_latent(k, F_, h, w) for k in range(51)]
+    masks = torch.from_numpy(pipeline_ref.mask_from_png_values(si.disc_masks(F_, h * 8, w * 8)))[None]
+    lat0 = pnp_utils.latent_adain(ci[50].half().cuda(), sy[50].half().cuda())
+    pnp_utils.register_spatial_attention_pnp(pipe)
+    keep = (19, 20, 22, 24, 25)
+    gflow = si.CountingFlow(h * 8, w * 8)
+    got, plain = {}, {}
+    torch.manual_seed(0)
+    out = pipe.video_style_transfer("", latents=lat0, num_inference_steps=50, content_inv_latents=ci, style_inv_latents=sy, masks=masks,
+                                    output_type="latent", smoother="pixel", flow_fn=lambda a, b: torch.from_numpy(gflow()).cuda(),
+                                    callback=lambda i, t, l: got.__setitem__(i, l.clone()) if i in keep else None).images
+    assert gflow.k == 5 * 2 * 58 and torch.isfinite(out.float()).all()
+    pipe.video_style_transfer("", latents=lat0, num_inference_steps=50, content_inv_latents=ci, style_inv_latents=sy, masks=masks, output_type="latent",
+                              callback=lambda i, t, l: plain.__setitem__(i, l.clone()) if i in keep else None)
+    osch = pipeline_ref.DDIMSchedule()
+    osch.set_timesteps(50)
+    oflow = si.CountingFlow(h * 8, w * 8)
+    ctx = text.half().float().expand(3, -1, -1).contiguous()
+    ref = {}
+    ofwd = dev_oracle(sd, cfg)
+    dvf = {k: t.cuda() for k, t in vf.items()}
+    dec = lambda z: vae_ref.decode(dvf, z.cuda().float(), z.shape[0], SMALL).cpu()
+    enc = lambda x: vae_ref.encode_moments(dvf, x.cuda().float(), SMALL)[:, :4].cpu()
+    with torch.no_grad():
+        pipeline_ref.video_style_transfer_loop(
+            lambda x, t, i: ofwd(x, t, ctx, pnp_idx=i, exact_temporal=False)[0],
+            osch, unet_ref.latent_adain(ci[50].half().float(), sy[50].half().float()), [t.half().float() for t in ci],
+            [t.half().float() for t in sy], masks, 50,
+            smoother=pipeline_ref.pixel_smoother(osch, dec, enc, oflow, masks.numpy()),
+            callback=lambda i, t, l: ref.__setitem__(i, l.clone()) if i in keep else None)
+    vals = {i: psnr(got[i], ref[i]) for i in keep}
+    off = {i: psnr(plain[i], ref[i]) for i in keep}
+    print("pixel smoother on the native VAE: PSNR native-vs-oracle", vals, "unsmoothed-vs-oracle", off)
+    assert all(v >= 35.0 for v in vals.values()), vals
+    assert all(vals[i] >= off[i] + 6.0 for i in (20, 22, 24)), (vals, off)

@@ -21,6 +21,11 @@ class UnetCfg(C.Structure):
                 ("freq_shift", C.c_float)]
 
 
+class VaeCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("block_out_channels", C.c_int * 4),
+                ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int)]
+
+
 class PnP(C.Structure):
     _fields_ = [("registered", C.c_int), ("idx", C.c_int), ("eta1", C.c_float), ("eta2", C.c_float),
                 ("alpha", C.c_float), ("gamma", C.c_float)]
@@ -66,6 +71,12 @@ SIGNATURES = {
     "univst_linear_ln": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P]),
     "univst_geglu_xres_permute": (_I, [_P, _P, _I, _I, _P]),
     "univst_frag_pack": (_I, [_P, _P, _I, _I, _P]),
+    "univst_vae_create": (_I, [_P, C.POINTER(_P)]),
+    "univst_vae_destroy": (_I, [_P]),
+    "univst_vae_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(C.c_int64), _I, _P]),
+    "univst_vae_finalize": (_I, [_P, _P]),
+    "univst_vae_decode": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "univst_vae_encode": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "univst_attn2_fused_workspace_bytes": (_L, [_I, _I, _I]),
     "univst_attn2_fused": (_I, [_P, _L, _P, _F, _P, _P, _P, _I, _P, _I, _I, _L, _P, _P, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),

@@ -69,7 +69,7 @@ class SpatioTemporalStableDiffusionPipeline:
             raise ImportError("Please install accelerate via `pip install accelerate`")
         device = torch.device(f"cuda:{gpu_id}")
         for m in (self.text_encoder, self.vae):
-            if m is not None:
+            if m is not None and not hasattr(m, "_h"):       # (a NativeTemporalVAE keeps its weights in the library, like the UNet)
                 cpu_offload(m, device)
 
     def prepare_extra_step_kwargs(self, generator, eta):

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "unet.h"
+#include "vae.h"
 
 static thread_local char g_err[1024] = "";
 void uv_set_error(const char* fmt, ...) {
@@ -138,6 +139,44 @@ int univst_linear_gated(const void* X, int64_t ldx, const void* W, const void* b
 int univst_geglu_xres_permute(const void* in, void* out, int rows, int cols, void* s) {
     UV_REQUIRE(in && out, "geglu_xres_permute: null argument");
     return uv_launch_geglu_xres_permute(H(in), HM(out), rows, cols, S(s));
+}
+struct univst_vae {
+    Vae impl;
+};
+int univst_vae_create(const univst_vae_cfg* cfg, univst_vae** out) {
+    UV_REQUIRE(cfg && out, "vae_create: null argument");
+    UV_REQUIRE(cfg->norm_num_groups > 0 && cfg->layers_per_block >= 1 && cfg->in_channels >= 1 && cfg->in_channels <= 8 && cfg->out_channels >= 1 &&
+               cfg->out_channels <= 8 && cfg->latent_channels >= 1 && cfg->latent_channels <= 8, "vae_create: bad config");
+    for (int i = 0; i < 4; ++i) {
+        const int c = cfg->block_out_channels[i];
+        UV_REQUIRE(c > 0 && c % 8 == 0 && c % cfg->norm_num_groups == 0 && (c / cfg->norm_num_groups) % 2 == 0,
+                   "vae_create: block_out_channels[%d]=%d must be a multiple of 8 and an even multiple of the group count", i, c);
+    }
+    univst_vae* h = new (std::nothrow) univst_vae();
+    UV_REQUIRE(h, "vae_create: out of host memory");
+    h->impl.cfg = *cfg;
+    *out = h;
+    return UV_OK;
+}
+int univst_vae_destroy(univst_vae* h) {
+    delete h;
+    return UV_OK;
+}
+int univst_vae_load_tensor(univst_vae* h, const char* key, const void* p, int dtype, const int64_t* shape, int ndim, void* s) {
+    UV_REQUIRE(h, "null handle");
+    return h->impl.load_tensor(key, p, dtype, shape, ndim, S(s));
+}
+int univst_vae_finalize(univst_vae* h, void* s) {
+    UV_REQUIRE(h, "null handle");
+    return h->impl.finalize(S(s));
+}
+int univst_vae_decode(univst_vae* h, const void* z, int64_t imgs, int num_frames, int lat_h, int lat_w, void* out, void* s) {
+    UV_REQUIRE(h && z && out, "vae_decode: null argument");
+    return h->impl.decode(H(z), imgs, num_frames, lat_h, lat_w, HM(out), S(s));
+}
+int univst_vae_encode(univst_vae* h, const void* x, int64_t imgs, int Hh, int W, void* moments, void* s) {
+    UV_REQUIRE(h && x && moments, "vae_encode: null argument");
+    return h->impl.encode(H(x), imgs, Hh, W, HM(moments), S(s));
 }
 int univst_frag_pack(const void* W, void* out, int N, int K, void* s) {
     UV_REQUIRE(W && out, "frag_pack: null argument");

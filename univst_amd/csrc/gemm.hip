@@ -716,9 +716,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             int hw = p.Ho * p.Wo;
             int img = m / hw, rem = m - img * hw;
             int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            int pad = (p.taps == 9) ? 1 : 0;
-            x_iy0[i] = oy * p.stride - pad;
-            x_ix0[i] = ox * p.stride - pad;
+            x_iy0[i] = oy * p.stride - p.pady;
+            x_ix0[i] = ox * p.stride - p.padx;
             x_img[i] = img * p.Hs;
         }
     }
@@ -766,8 +765,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < XL; ++i) glds16((x_ok[i] && kok) ? xptr[i] + k0 : uv_zero_page, Xd + RPP * i * LDSH);
         } else {
-            const int ky = (p.taps == 9) ? tap / 3 : 0;
-            const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
+            const int ky = (p.tapw == 3) ? tap / 3 : tap;        // tapw = taps per kernel row: 3 (3x3), 1 (1x1 and the 3x1 frame conv)
+            const int kx = (p.tapw == 3) ? tap - 3 * ky : 0;
             const int He = p.Hs << p.up, We = p.Ws << p.up;
             const bool src2 = cc >= p.C1;
             const half_t* base = src2 ? p.X2 : p.X;
@@ -991,16 +990,15 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
             int hw = p.Ho * p.Wo;
             int img = m / hw, rem = m - img * hw;
             int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            int pad = (p.taps == 9) ? 1 : 0;
-            x_iy0[i] = oy * p.stride - pad;
-            x_ix0[i] = ox * p.stride - pad;
+            x_iy0[i] = oy * p.stride - p.pady;
+            x_ix0[i] = ox * p.stride - p.padx;
             x_img[i] = img * p.Hs;
         }
     }
     // Fast im2col addressing for the common case (3x3, tap-inner k order, no fused upsample): the pixel offset of tap
     // (ky, kx) is the row's own base plus a wave-uniform delta, and padding validity is a 9-bit mask per row computed
     // once — 3 VALU per DMA instead of ~25 (the conv kernel issued 149 non-MFMA VALU per 80 MFMAs; tools/pmc_gemm.sh).
-    const bool fast_conv = MODE == 1 && p.korder && p.up == 0 && p.taps == 9;
+    const bool fast_conv = MODE == 1 && p.korder && p.up == 0 && p.taps == 9;      // (korder implies the symmetric 3x3: launcher)
     int x_pix0[MJ];
     unsigned x_mask[MJ];
     if (MODE == 1) {
@@ -1064,8 +1062,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
                 glds16(ok ? base + (long)x_pix0[i] * cs + delta : zp, Xd + 64 * i * LDSH);
             }
         } else {
-            const int ky = (p.taps == 9) ? tap / 3 : 0;
-            const int kx = (p.taps == 9) ? tap - 3 * ky : 0;
+            const int ky = (p.tapw == 3) ? tap / 3 : tap;        // tapw = taps per kernel row: 3 (3x3), 1 (1x1 and the 3x1 frame conv)
+            const int kx = (p.tapw == 3) ? tap - 3 * ky : 0;
             const int He = p.Hs << p.up, We = p.Ws << p.up;
             const bool src2 = cc >= p.C1;
             const half_t* base = src2 ? p.X2 : p.X;
@@ -1504,7 +1502,12 @@ bool uv_linear_fold_consumer_ok(long M, int N, int K, bool geglu) {
     return small_plan(M, N, K, false, 0, false).splits == 1;
 }
 
-int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
+int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
+    GemmParams p = p0;
+    if (mode == 1 && p.tapw == 0) {       // kernel geometry defaults: 3x3 with padding 1, 1x1 without
+        p.tapw = p.taps == 9 ? 3 : 1;
+        p.pady = p.padx = p.taps == 9 ? 1 : 0;
+    }
     UV_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     if (p.geglu == 2) {                  // weights in the X-resident kernel's row order (geglu_xres_kernel)
         auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -1529,9 +1532,11 @@ int uv_launch_gemm(const GemmParams& p, int mode, hipStream_t stream) {
         UV_REQUIRE(p.ldx % 8 == 0, "gemm: ldx=%ld must be a multiple of 8", p.ldx);
     } else {
         UV_REQUIRE(p.C1 % 8 == 0 && p.C2 % 8 == 0, "conv: channel counts must be multiples of 8 (C1=%d C2=%d)", p.C1, p.C2);
-        UV_REQUIRE(p.taps == 1 || p.taps == 9, "conv: taps=%d", p.taps);
+        UV_REQUIRE((p.taps == 1 && p.tapw == 1) || (p.taps == 9 && p.tapw == 3) || (p.taps == 3 && p.tapw == 1), "conv: taps=%d with %d per row (1x1, 3x3 or the 3x1 frame conv)", p.taps, p.tapw);
         UV_REQUIRE(p.K == p.taps * (p.C1 + p.C2), "conv: K=%d != taps*(C1+C2)", p.K);
-        UV_REQUIRE(!p.korder || (p.taps == 9 && p.C1 % 64 == 0 && p.C2 % 64 == 0), "conv: tap-inner k order needs taps=9 and 64-channel slabs");
+        const bool sym3 = p.taps == 9 && p.pady == 1 && p.padx == 1;
+        UV_REQUIRE(!p.korder || (sym3 && p.C1 % 64 == 0 && p.C2 % 64 == 0), "conv: tap-inner k order needs the 3x3 / padding-1 kernel and 64-channel slabs");
+        UV_REQUIRE(!p.W32 || sym3, "conv: the LDS-patch weight copy is for the 3x3 / padding-1 kernel");
     }
     {   // large-M path: 256x320 tiles when they tile N exactly and fill the chip (>= 2 blocks per CU)
         const int nobig = big_env().nobig;

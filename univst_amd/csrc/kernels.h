@@ -13,6 +13,10 @@ struct GemmParams {
     int M = 0, N = 0, K = 0;
     // MODE 1 geometry
     int C1 = 0, C2 = 0, Hs = 1, Ws = 1, up = 0, Ho = 1, Wo = 1, stride = 1, taps = 1;
+    // kernel geometry (0 = the launcher's default: 3x3 with padding 1 for taps = 9, 1x1 for taps = 1).  Explicit forms (round 5, the VAE): the 3x1
+    // frame conv of a Conv3d (3,1,1) on the geometry "image rows = frames, image columns = pixels" (taps = 3, tapw = 1, pady = 1, padx = 0) and the
+    // encoder's stride-2 conv over the input padded at the bottom / right only (taps = 9, tapw = 3, pady = padx = 0)
+    int tapw = 0, pady = 0, padx = 0;
     // korder 0: K index = tap*(C1+C2) + c.  korder 1 ("tap-inner", needs C1 % 64 == C2 % 64 == 0, taps == 9):
     // K index = (c/64)*576 + tap*64 + c%64 — the 9 taps of one 64-channel slab are consecutive k tiles, so the
     // activation rows a block re-reads for the shifted taps are still in its XCD's L2 (9x less beyond-L2 traffic).

@@ -1,8 +1,9 @@
 """Shared pieces of the three SD-v1.5 command-line entry points (mirrors of src/sd/run_*_sd.py of the reference).
 
-CLIP (transformers) and the SVD temporal VAE (diffusers) are third-party models and stay stock PyTorch-ROCm
-modules; they must be available locally — there is no hub access on the target boxes.  The
-UNet, the DDIM loops, the PnP injection, mask blending and AdaIN run in the native HIP library."""
+CLIP (transformers) is a third-party model and stays a stock PyTorch-ROCm module; the SVD temporal VAE is LOADED through diffusers
+(its checkpoint format and config) and then runs on the native library (univst_amd.vae.NativeTemporalVAE takes the stock module's state dict;
+round 5, SURVEY §8 f2 — ``UNIVST_VAE=stock`` keeps the diffusers module).  Both must be available locally — there is no hub access on the target
+boxes.  The UNet, the DDIM loops, the PnP injection, mask blending and AdaIN run in the native HIP library."""
 import os
 
 import torch
@@ -21,8 +22,12 @@ def build_pipeline(pretrained_model_path, weight_dtype=torch.float16, vae_path="
     text_encoder = CLIPTextModel.from_pretrained(pretrained_model_path, subfolder="text_encoder").requires_grad_(False)
     vae = AutoencoderKLTemporalDecoder.from_pretrained(vae_path, subfolder="vae").requires_grad_(False)
     unet = UNetPseudo3DConditionModel.from_2d_model(os.path.join(pretrained_model_path, "unet")).requires_grad_(False)
+    vae = vae.to(weight_dtype).cuda()
+    if os.environ.get("UNIVST_VAE", "native") != "stock":
+        from ...vae import NativeTemporalVAE
+        vae = NativeTemporalVAE.from_module(vae)
     pipe = SpatioTemporalStableDiffusionPipeline(
-        vae=vae.to(weight_dtype).cuda(), text_encoder=text_encoder.to(weight_dtype).cuda(), tokenizer=tokenizer,
+        vae=vae, text_encoder=text_encoder.to(weight_dtype).cuda(), tokenizer=tokenizer,
         unet=unet.to(weight_dtype).cuda(), scheduler=DDIMScheduler.from_pretrained(pretrained_model_path, subfolder="scheduler"))
     return pipe, DDIMScheduler
 

@@ -100,3 +100,75 @@ def synth_flow(H, W, dx, dy, seed, noise=0.25, device="cuda"):
     f[..., 0] = dx
     f[..., 1] = dy
     return (f + noise * torch.randn(H, W, 2, generator=g)).to(device)
+
+
+SVD_VAE_CONFIG = dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                      norm_num_groups=32, scaling_factor=0.18215)
+
+
+def vae_state_dict(config=None, device="cuda", dtype=torch.float16, seed=7):
+    """Random-init state dict with the parameter names and shapes of diffusers' AutoencoderKLTemporalDecoder (the SVD VAE; no checkpoint exists on
+    the target boxes): fan-in scaled convolutions / linears, near-unit norms, mix factors around 0 (sigmoid = 0.5: both branches of every
+    SpatioTemporalResBlock matter).  Key list restated from the published class (univst_amd/csrc/vae.hip header)."""
+    cfg = dict(SVD_VAE_CONFIG if config is None else config)
+    boc, L, lat = cfg["block_out_channels"], cfg["layers_per_block"], cfg["latent_channels"]
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+
+    def rn(*shape):
+        return torch.randn(*shape, generator=g, device=device, dtype=torch.float32)
+
+    def conv(p, co, ci, *k):
+        fan = ci
+        for d in k:
+            fan *= d
+        sd[p + ".weight"] = (rn(co, ci, *k) / math.sqrt(fan)).to(dtype)
+        sd[p + ".bias"] = (0.02 * rn(co)).to(dtype)
+
+    def lin(p, co, ci):
+        sd[p + ".weight"] = (rn(co, ci) / math.sqrt(ci)).to(dtype)
+        sd[p + ".bias"] = (0.02 * rn(co)).to(dtype)
+
+    def norm(p, c):
+        sd[p + ".weight"] = (1.0 + 0.1 * rn(c)).to(dtype)
+        sd[p + ".bias"] = (0.05 * rn(c)).to(dtype)
+
+    def resnet(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", co, ci, 3, 3); norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3, 3)
+        if ci != co:
+            conv(p + ".conv_shortcut", co, ci, 1, 1)
+
+    def st(p, ci, co):
+        resnet(p + ".spatial_res_block", ci, co)
+        t = p + ".temporal_res_block"
+        norm(t + ".norm1", co); conv(t + ".conv1", co, co, 3, 1, 1); norm(t + ".norm2", co); conv(t + ".conv2", co, co, 3, 1, 1)
+        sd[p + ".time_mixer.mix_factor"] = (0.5 * rn(1)).to(dtype)
+
+    def attn(p, c):
+        norm(p + ".group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(p + "." + n, c, c)
+
+    conv("encoder.conv_in", boc[0], cfg["in_channels"], 3, 3)
+    ci = boc[0]
+    for b in range(4):
+        for l in range(L):
+            resnet(f"encoder.down_blocks.{b}.resnets.{l}", ci, boc[b]); ci = boc[b]
+        if b < 3:
+            conv(f"encoder.down_blocks.{b}.downsamplers.0.conv", boc[b], boc[b], 3, 3)
+    resnet("encoder.mid_block.resnets.0", boc[3], boc[3]); attn("encoder.mid_block.attentions.0", boc[3]); resnet("encoder.mid_block.resnets.1", boc[3], boc[3])
+    norm("encoder.conv_norm_out", boc[3]); conv("encoder.conv_out", 2 * lat, boc[3], 3, 3); conv("quant_conv", 2 * lat, 2 * lat, 1, 1)
+    conv("decoder.conv_in", boc[3], lat, 3, 3)
+    for l in range(L):
+        st(f"decoder.mid_block.resnets.{l}", boc[3], boc[3])
+    attn("decoder.mid_block.attentions.0", boc[3])
+    ci = boc[3]
+    for b in range(4):
+        co = boc[3 - b]
+        for l in range(L + 1):
+            st(f"decoder.up_blocks.{b}.resnets.{l}", ci, co); ci = co
+        if b < 3:
+            conv(f"decoder.up_blocks.{b}.upsamplers.0.conv", co, co, 3, 3)
+    norm("decoder.conv_norm_out", boc[0]); conv("decoder.conv_out", cfg["out_channels"], boc[0], 3, 3)
+    conv("decoder.time_conv_out", cfg["out_channels"], cfg["out_channels"], 3, 1, 1)
+    return sd
