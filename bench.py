@@ -163,10 +163,12 @@ def cpu_baseline(frames_full, unet=None, full=False, single_branch=False, quick=
         t_out, scale = t_in * ratio, 1.0
         how = (f"one {'single-branch' if single_branch else 'three-branch'} UNet step inside the PnP window MEASURED at the full F={frames_full}: {t_in:.1f} s; "
                f"the out-of-window step taken as x{ratio:.3f} (ratio of the two kinds of step at F=2: {a_in:.1f} s in-window)")
-        extrap = False
+        extrap = False if single_branch else "ratio"      # 24 of the 50 step times are DERIVED (in-window time at full F x the F = 2 ratio), not measured
     # the 50-step loop has 26 steps inside the window (i = 0..25) and 24 outside; per-step cost has no other data dependence
     loop_full = (26 * t_in + 24 * t_out) * scale
-    return dict(value=frames_full / loop_full, unit="frames/s", cores=cores, kind="port", extrapolated=extrap,
+    method = "full" if full else ("quick_F2_linear" if quick else "inwindow_fullF_outwindow_ratio")
+    return dict(value=frames_full / loop_full, unit="frames/s", cores=cores, kind="port", extrapolated=extrap, method=method, method_since_round=4 if method.startswith("inwindow") else 1,
+                derived_out_of_window=(method == "inwindow_fullF_outwindow_ratio" and not single_branch),
                 sample=f"{how}; fp32, all temporal ops, 64x64 latents, on {cores} threads (cgroup quota); weighted to 26 + 24 steps "
                        f"(weight copy {t1 - t0:.0f} s excluded)")
 
@@ -618,6 +620,7 @@ def main():
         sync()
     if rank == 0 and not a.no_profile:
         prof = _native.profile_collect()
+        launched = _native.profile_symbols()
         _native.profile_enable(False)
         classes = {}
         for k, v in prof.items():
@@ -645,6 +648,13 @@ def main():
             pat = {"gemm_big_kernel<0>": r"gemm_big_kernel<0,|geglu_xres_kernel<", "gemm_big_kernel<1>": r"gemm_big_kernel<1,", "conv_patch_kernel": r"conv_patch_kernel<",
                    "attn_pp40_kernel<true>": r"attn_pp40_kernel<true,0[,>]"}.get(dom, re.escape(dom.replace(" ", "")))
             hit = [v for k, v in pm.items() if re.search(pat, k.replace(" ", ""))]
+            # every symbol this run launched in the class must have its counters in that file (a kernel added since the PMC passes has none:
+            # quoting the file's mean would then describe another set of kernels) — else traffic stays null and the line says what is missing
+            missing = [sy for sy in launched.get(dom, []) if not any(sy in k.replace(" ", "") for k in pm)]
+            out["roofline"]["symbols_launched"] = launched.get(dom, [])
+            if missing:
+                out["roofline"]["traffic_source"] = f"profiles/{cands[-1]} has no counters for {missing}: traffic not quoted (re-run tools/refresh_profiles.sh)"
+                hit = []
             if hit and world == 1:      # a class may span several symbols (the 256- and 192-row tile): launch-weighted mean
                 nl = sum(v["launches_sampled"] for v in hit)
                 out["roofline"]["traffic"] = int(sum(v["hbm_bytes_per_launch_corrected"] * v["launches_sampled"] for v in hit) / max(nl, 1))

@@ -27,6 +27,10 @@ extern "C" {
 #define UNIVST_F32 1
 
 const char* univst_last_error(void);
+/* Bumped whenever an existing entry changes its signature or meaning (2: univst_sd3_joint_attention takes (shift, beta) instead of the
+ * window parameters, round 4).  A binding checks it at load time (univst_amd/_native.py does): a caller built against an older header would
+ * otherwise pass silently misinterpreted arguments. */
+#define UNIVST_ABI_VERSION 2
 int univst_abi_version(void);
 
 /* ------------------------------------------------------------------ UNet handle
@@ -258,6 +262,9 @@ typedef struct {
     const void *res_img, *gate_img, *res_txt, *gate_txt;
     int64_t ld_gate_img, ld_gate_txt;
 } univst_sd3_gated_residual;
+/* the window test and beta of AttentionShiftProcessor in double (pnp_utils.py:183-186, fixed reading thresh2 == eta2), for callers outside Python:
+ * active = eta1*50 <= idx <= eta2*50, beta = 0.9 -> 0.1 over the window (0 outside).  Pass (shift = active, beta) to univst_sd3_joint_attention. */
+int univst_sd3_shift_window(int idx, double eta1, double eta2, int* active, float* beta);
 int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hidden, const void* enc, int B, int N, int Nt, int Cin,
                                int heads, int head_dim, int clip_length, int shift, float beta, float rms_eps,
                                void* out_img, void* out_txt, const univst_sd3_gated_residual* gated_residual /* may be NULL */,
@@ -357,6 +364,10 @@ int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n,
 #define UNIVST_PROFILE_CLASSES 13
 int univst_profile_enable(int on);
 int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int nclasses);
+/* ';'-joined kernel symbols launched in class `cls` since profiling was last switched on (template arguments without spaces, e.g.
+ * "gemm_big_kernel<0,4,2>"; classes whose launchers do not name their kernels give ""): bench.py quotes PMC traffic only when every one of them
+ * has an entry in the committed counter file */
+int univst_profile_symbols(int cls, char* buf, int n);
 
 /* bring-up aid: what ds_read_b64_tr_b16 returns per lane for a known LDS image (256 floats) */
 int univst_debug_tr16(float* out256, void* stream);

@@ -37,7 +37,9 @@ def test_exports_match_header(lib):
 
 
 def test_version_and_error_string(lib):
-    assert lib.univst_abi_version() == 1
+    from univst_amd import _native
+    src = open(os.path.join(ROOT, "include", "univst.h")).read()
+    assert lib.univst_abi_version() == _native.ABI_VERSION == int(re.search(r"#define UNIVST_ABI_VERSION (\d+)", src).group(1)) == 2
     assert isinstance(lib.univst_last_error(), bytes)
 
 
@@ -127,3 +129,15 @@ def test_sd3_attention_parameters_are_kept_as_consecutive_views():
         assert b.data_ptr() - a.data_ptr() == step and c.data_ptr() - b.data_ptr() == step and a.dtype == torch.float16 and a.is_contiguous()
     assert torch.equal(p["to_k"], sd["to_k.weight"].half()) and torch.equal(p["add_v"], sd["add_v_proj.weight"].half())
     assert "add_q_bias" not in p and "to_out" in p and "norm_q" not in p
+
+
+def test_sd3_shift_window_helper_matches_the_reference_formula(lib):
+    """univst_sd3_shift_window: the window test and beta of AttentionShiftProcessor (pnp_utils.py:183-186) in double — a host-only entry, callable
+    without a GPU; idx 15 with eta1 = 0.3 is INSIDE the window (fp32 would put it outside)"""
+    import ctypes as C
+    for idx, e1, e2 in [(15, 0.3, 0.6), (14, 0.3, 0.6), (30, 0.3, 0.6), (31, 0.3, 0.6), (0, 0.0, 0.6), (22, 0.3, 0.6)]:
+        a, b = C.c_int(-1), C.c_float(-1.0)
+        assert lib.univst_sd3_shift_window(idx, e1, e2, C.byref(a), C.byref(b)) == 0
+        active = idx >= e1 * 50 and idx <= e2 * 50
+        beta = ((0.9 - 0.1) / (e1 * 50 - e2 * 50) * (idx - e2 * 50) + 0.1) if active else 0.0
+        assert bool(a.value) == active and abs(b.value - beta) < 1e-6, (idx, a.value, b.value, beta)

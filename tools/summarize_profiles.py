@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, shutil, sys
 
 O = sys.argv[1]
-RND = os.environ.get("ROUND", "3")
+RND = os.environ.get("ROUND", "5")
 
 def one(pattern):
     hits = glob.glob(os.path.join(O, "raw", pattern), recursive=True)

@@ -50,6 +50,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "univst_last_error": (C.c_char_p, []),
     "univst_abi_version": (_I, []),
+    "univst_sd3_shift_window": (_I, [_I, C.c_double, C.c_double, C.POINTER(_I), C.POINTER(_F)]),
     "univst_unet_create": (_I, [C.POINTER(UnetCfg), C.POINTER(_P)]),
     "univst_unet_destroy": (_I, [_P]),
     "univst_unet_load_tensor": (_I, [_P, C.c_char_p, _P, _I, C.POINTER(_L), _I, _P]),
@@ -115,8 +116,12 @@ SIGNATURES = {
     "univst_window_store": (_I, [_P, _F, _P, _L, _P]),
     "univst_debug_tr16": (_I, [_P, _P]),
     "univst_profile_enable": (_I, [_I]),
+    "univst_profile_symbols": (_I, [_I, C.c_char_p, _I]),
     "univst_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
 }
+
+
+ABI_VERSION = 2      # include/univst.h UNIVST_ABI_VERSION
 
 
 def lib_path() -> str:
@@ -135,6 +140,9 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        if lib.univst_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{_LIB_PATH} has ABI version {lib.univst_abi_version()}, this binding was written against {ABI_VERSION} "
+                               "(include/univst.h UNIVST_ABI_VERSION): rebuild the library (`make`)")
         _lib = lib
     return _lib
 
@@ -536,6 +544,16 @@ PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>
 
 def profile_enable(on: bool):
     check(load().univst_profile_enable(int(on)), "profile_enable")
+
+
+def profile_symbols():
+    """-> {class: [kernel symbols launched since profile_enable(True)]}"""
+    out = {}
+    for i, name in enumerate(PROFILE_CLASSES):
+        buf = C.create_string_buffer(2048)
+        check(load().univst_profile_symbols(i, buf, 2048), "profile_symbols")
+        out[name] = [s for s in buf.value.decode().split(";") if s]
+    return out
 
 
 def profile_collect():

@@ -32,7 +32,15 @@ struct univst_unet {
 extern "C" {
 
 const char* univst_last_error(void) { return g_err; }
-int univst_abi_version(void) { return 1; }
+int univst_abi_version(void) { return UNIVST_ABI_VERSION; }
+int univst_sd3_shift_window(int idx, double eta1, double eta2, int* active, float* beta) {
+    UV_REQUIRE(active && beta, "sd3_shift_window: null argument");
+    // pnp_utils.py:183-186 in double, as the reference's Python evaluates it (in fp32, 0.3f * 50 = 15.000001 and step 15 falls out of the window)
+    const bool on = eta1 * 50 <= (double)idx && (double)idx <= eta2 * 50;
+    *active = on ? 1 : 0;
+    *beta = on ? (float)((0.9 - 0.1) / (eta1 * 50 - eta2 * 50) * ((double)idx - eta2 * 50) + 0.1) : 0.f;
+    return UV_OK;
+}
 
 int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     UV_REQUIRE(cfg && out, "unet_create: null argument");
@@ -324,6 +332,12 @@ int univst_mask_resize(const uint8_t* mask, void* out, int F, int Hh, int W, int
 int univst_debug_tr16(float* out, void* s) { return uv_launch_tr16_probe(out, S(s)); }
 int univst_profile_enable(int on) {
     uv_prof_enable(on);
+    return UV_OK;
+}
+int univst_profile_symbols(int cls, char* buf, int n) {
+    UV_REQUIRE(buf && n > 0, "profile_symbols: null buffer");
+    const std::string sy = uv_prof_symbols(cls);
+    snprintf(buf, (size_t)n, "%s", sy.c_str());
     return UV_OK;
 }
 int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int ncls) {

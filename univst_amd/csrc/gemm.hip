@@ -1515,7 +1515,8 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
                    !p.R && !p.rowbias && !p.bias2 && !p.stats_out && !p.act && !p.gate && !p.gn_out && (long)p.M * p.ldx < (1L << 31) &&
                    (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0 && !p.bias)),
                    "geglu (X-resident order): needs K = 320, N %% 256 == 0, 16-byte aligned rows, no residual / second bias (M=%d N=%d K=%d)", p.M, p.N, p.K);
-        uv_prof_begin(UV_CLS_GEMM_BIG, 2.0 * p.M * (double)p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.N / 2)), stream);
+        uv_prof_begin(UV_CLS_GEMM_BIG, 2.0 * p.M * (double)p.N * p.K, 2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.N / 2)), stream,
+                      p.ln_stats ? "geglu_xres_kernel<2>" : "geglu_xres_kernel<0>");
         const dim3 grid((p.M + XR_BM - 1) / XR_BM);
         if (p.ln_stats) hipLaunchKernelGGL((geglu_xres_kernel<2>), grid, dim3(512), 0, stream, p);
         else hipLaunchKernelGGL((geglu_xres_kernel<0>), grid, dim3(512), 0, stream, p);
@@ -1569,8 +1570,11 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
         UV_REQUIRE(p.W || use_patch, "conv: only the [Cin/32][9][32] weight copy was given but the problem is not eligible for the LDS-patch kernel "
                    "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles or a reduction long enough for split-K)");
         if (big_shape_ok(p.N, p.K, xmax, ragged) && (nblk >= bigmin || bsplits > 1)) {
+            char sym[48];
+            if (use_patch) snprintf(sym, sizeof sym, "conv_patch_kernel<%d>", use192 ? 3 : 4);
+            else snprintf(sym, sizeof sym, "gemm_big_kernel<%d,%d,%d>", mode, use192 ? 3 : 4, mode == 0 ? (p.ln_stats ? 2 : (p.stats_out ? 1 : (mmdit_epi ? 3 : 0))) : 0);
             uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K,
-                          2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
+                          2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream, sym);
             // row-contiguous epilogue through LDS needs 16-byte aligned rows everywhere it touches; it pays for the plain
             // and residual epilogues (-12..19 % at K=320) but not for GEGLU, whose stores are half as many (UNIVST_GEMM_EPI=2 forces it)
             const int epi = big_env().epi;

@@ -1,6 +1,7 @@
 // Internal launcher interface shared by the kernel translation units, the UNet graph and the C ABI.
 #pragma once
 #include "common.h"
+#include <string>
 
 struct GemmParams {
     // Y[m][n] = epilogue(sum_k X[m][k] W[n][k])
@@ -196,6 +197,7 @@ enum {
 };
 void uv_prof_enable(int on);
 bool uv_prof_on();
-void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s);
+void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s, const char* sym = nullptr);     // sym: the kernel symbol about to be launched (template arguments without spaces)
 void uv_prof_end(hipStream_t s);
 int uv_prof_collect(double* ms, long* count, double* flops, double* bytes, int ncls);
+std::string uv_prof_symbols(int cls);           // ';'-joined symbols launched in that class since profiling was switched on

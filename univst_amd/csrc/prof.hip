@@ -1,4 +1,6 @@
 // Optional per-kernel-class HIP-event timing (bench.py roofline leg).  Off by default: zero overhead.
+#include <set>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -12,12 +14,24 @@ struct Rec {
 };
 bool g_on = false;
 std::vector<Rec> g_recs;
+std::set<std::string> g_syms[UV_NCLS];       // kernel symbols launched per class since the last enable(1) (bench.py checks its PMC file against them)
 }  // namespace
 
-void uv_prof_enable(int on) { g_on = on != 0; }
+void uv_prof_enable(int on) {
+    if (on && !g_on)
+        for (auto& st : g_syms) st.clear();
+    g_on = on != 0;
+}
+std::string uv_prof_symbols(int cls) {
+    std::string out;
+    if (cls < 0 || cls >= UV_NCLS) return out;
+    for (const std::string& sy : g_syms[cls]) out += (out.empty() ? "" : ";") + sy;
+    return out;
+}
 bool uv_prof_on() { return g_on; }
-void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s) {
+void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s, const char* sym) {
     if (!g_on) return;
+    if (sym && cls >= 0 && cls < UV_NCLS) g_syms[cls].insert(sym);
     Rec r{cls, nullptr, nullptr, flops, bytes};
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);

@@ -440,7 +440,12 @@ int UNet::finalize(hipStream_t s) {
             if (rc) return rc;
             hipLaunchKernelGGL(geglu_interleave_kernel, dim3(nb((long)rows * cols)), dim3(256), 0, s, t.ptr, d, rows, cols);
             // K = 320 (the 64x64 level): a second copy in the row order of the X-resident kernel (gemm.hip geglu_xres_kernel)
-            const int kdim = ends(k, ".weight") ? cols : (int)weights[k.substr(0, k.size() - strlen("bias")) + "weight"].shape[1];
+            int kdim = cols;
+            if (!ends(k, ".weight")) {      // the bias: the reduction length is its weight's (a checkpoint that carries the bias without the weight is refused)
+                const WTensor* wt = find(k.substr(0, k.size() - strlen("bias")) + "weight");
+                UV_REQUIRE(wt && wt->shape.size() == 2, "%s: the projection's weight is missing", k.c_str());
+                kdim = (int)wt->shape[1];
+            }
             if (uv_geglu_xres_ok(rows, kdim)) {
                 half_t* dx;
                 rc = derive_alloc(k + "#xres", {rows, cols}, &dx);
@@ -562,7 +567,9 @@ int UNet::finalize(hipStream_t s) {
 
 int UNet::reserve(int B, int F, int H, int Wd) {
     const long rows0 = (long)B * F * H * Wd;
-    size_t need = (size_t)rows0 * cfg.block_out_channels[0] * 2 * 28 + (64u << 20) + UV_SPLITK_WS_BYTES;
+    // activations (28 level-0-sized tensors at the high-water mark of the graph) + the small workspaces + split-K partials + the pool of the
+    // producers' GroupNorm statistics (Fwd::gst_pool: rows0 / 16 fragments x 32 sub-group slots x 64 tensors x (sum, sumsq) fp32 = 1 KB per row)
+    size_t need = (size_t)rows0 * cfg.block_out_channels[0] * 2 * 28 + (64u << 20) + UV_SPLITK_WS_BYTES + (gn_producer ? (size_t)rows0 * 1024 : 0);
     if (arena.size < need) {
         UV_HIP(hipDeviceSynchronize());
         if (arena.base) UV_HIP(hipFree(arena.base));
@@ -1045,6 +1052,7 @@ struct Fwd {
             if (!h4 && !(h4 = alloc(rows * C))) return UV_ERR_STATE;
             RUN(linear(mid, 4 * C, brows, 4 * C, b + ".ff.net.2.weight", b + ".ff.net.2.bias", C, h4 + o, C, h3 + o, C, t_attn ? nullptr : tb));
         }
+        ap.BF = x.imgs;                // (the band loop narrowed it)
         if (nbands > 1) {
             free(h);
             free(q2);
@@ -1128,7 +1136,8 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     f.ad_ws = (float*)arena.alloc((size_t)F * 2 * boc[3] * 2 * sizeof(float) + 1024);
     f.sk_ws = (float*)arena.alloc(UV_SPLITK_WS_BYTES);
     UV_REQUIRE(f.gn_ws && f.ad_ws && f.sk_ws, "forward: arena too small");
-    if (gn_producer) {             // statistics of up to 64 level-0-sized tensors: [rows/16][G][2] fp32 each (3 MB at 3 x 16 x 64 x 64)
+    if (gn_producer) {             // statistics of up to 64 level-0-sized tensors: [rows/16][G][2] fp32 each (3 MB per tensor at 3 x 16 x 64 x 64: 201 MB, counted in
+                                   // reserve()); taken AFTER the mandatory workspaces, so it is the part that degrades first (consumers fall back to their own pass)
         f.gst_left = (size_t)(((long)B * F * H * Wd + 15) / 16) * cfg.norm_num_groups * 2 * 64;
         f.gst_pool = (float*)arena.alloc(f.gst_left * sizeof(float));
         if (!f.gst_pool) f.gst_left = 0;

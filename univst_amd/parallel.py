@@ -250,8 +250,12 @@ class FrameShard:
             if self.rank == 0:
                 print(f"[univst_amd] frame-sharded forward through {kind} differs from the unsharded one (max rel err {err}); "
                       "switching to the torch.distributed callbacks", flush=True)
+            rejected = self.comm
             self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
             self._handle, self._tokens, self.ws = None, 0, None
+            with self.detached(unet):                      # the UNet lets go of the rejected communicator's regions ...
+                if hasattr(rejected, "close"):
+                    rejected.close()                       # ... before they are unmapped, on all ranks together
             self.ensure(unet, xf.shape[-1] * xf.shape[-2])
             err2 = once()
             self.report = {"comm": type(self.comm).__name__, "max_rel_err_vs_unsharded": err2, "rejected": {"comm": kind, "max_rel_err": err}}
@@ -459,6 +463,19 @@ class NativeIpcComm:
 
     def abort(self):
         pass
+
+    def close(self):
+        """Retire this communicator on ALL ranks together (a collective): every rank drains its stream and meets the others at a host barrier
+        before anyone unmaps / frees the regions — a peer's kernel may still be writing into this rank's region through its IPC mapping.
+        (Device-side waits are bounded — tens of seconds, csrc/comm.hip — so a rank whose sharded forward waits for a dead peer does reach
+        this point.)"""
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+        if self.ptr is not None:
+            _native.load().univst_comm_destroy(self.ptr)
+            self.ptr = None
 
     def __del__(self):
         try:
