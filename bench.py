@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--comm", default=None, choices=["ipc", "dist"],
                     help="frame-shard communicator for --gpus > 1: ipc = the library's own (HIP IPC peer writes + device flags, no host "
                          "callbacks; default, falls back to dist if the mapping fails), dist = torch.distributed callbacks (RCCL / gloo)")
+    ap.add_argument("--emulate-wire", default=None, metavar="GBPS[,LAT_US]",
+                    help="with --emulate-rank: model the wire too — every K/V exchange keeps the stream busy for pack bytes / GBPS (per-direction rate of one "
+                         "xGMI link; rank 1's link from rank 0 carries two packs) and every GroupNorm all-reduce for LAT_US (default 3); serial, as csrc/comm.hip "
+                         "issues them today")
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
@@ -520,7 +524,8 @@ def main():
         from univst_amd.parallel import NullComm
         er, ew = (int(v) for v in a.emulate_rank.split("/"))
         emu = (er, ew)
-        shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew))
+        wire = [float(v) for v in a.emulate_wire.split(",")] if a.emulate_wire else None
+        shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew, *(wire or [])))
     else:
         shard = FrameShard(rank, world, F_total)
     unet = synth.build_unet(config=synth.SD21_UNET_CONFIG if a.model == "sd21" else None, device=dev, seed=33)
@@ -579,11 +584,14 @@ def main():
     for i in range(a.warmup):
         lat = step(i % 50, lat)
     sync()
+    if emu is not None:
+        shard.comm.wire_us = 0.0
     t0 = time.perf_counter()
     for i in idx:
         lat = step(i, lat)
     sync()
     dt = time.perf_counter() - t0
+    wire_ms_per_step = (shard.comm.wire_us / a.steps / 1e3) if emu is not None and a.emulate_wire else None
     if dist is not None:
         tmax = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -602,8 +610,9 @@ def main():
                                 f"{a.model}_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "schedule_steps": "all 50" if a.steps == 50 else (f"{a.steps} of 50, evenly spread" if a.steps < 50 else f"{a.steps} (wrapping modulo 50)"),
-                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} (no wire)" if emu else "single") if world == 1 else f"frames{world}",
+                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} ({'wire modelled at ' + a.emulate_wire + ' GB/s per link, serial' if a.emulate_wire else 'no wire'})" if emu else "single") if world == 1 else f"frames{world}",
                    "comm": None if world == 1 else type(shard.comm).__name__, "shard_check": shard_check,
+                   **({"modelled_wire_ms_per_step": round(wire_ms_per_step, 3)} if wire_ms_per_step is not None else {}),
                    "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else
                                "random-init SD-v1.5 architecture (859M + 201M temporal params), fp16")},
     }

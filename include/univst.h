@@ -371,6 +371,9 @@ int univst_profile_symbols(int cls, char* buf, int n);
 
 /* bring-up aid: what ds_read_b64_tr_b16 returns per lane for a known LDS image (256 floats) */
 int univst_debug_tr16(float* out256, void* stream);
+/* measurement aid (bench.py --emulate-wire): a one-thread kernel that keeps `stream` busy for `us` microseconds — the stand-in for a transfer of
+ * bytes / link rate when one rank of a multi-GPU job is emulated on a 1-GPU box */
+int univst_debug_delay_us(double us, void* stream);
 
 #ifdef __cplusplus
 }

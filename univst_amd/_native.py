@@ -115,6 +115,7 @@ SIGNATURES = {
     "univst_accumulate_u8": (_I, [_P, _P, _L, _P]),
     "univst_window_store": (_I, [_P, _F, _P, _L, _P]),
     "univst_debug_tr16": (_I, [_P, _P]),
+    "univst_debug_delay_us": (_I, [C.c_double, _P]),
     "univst_profile_enable": (_I, [_I]),
     "univst_profile_symbols": (_I, [_I, C.c_char_p, _I]),
     "univst_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
@@ -535,6 +536,10 @@ def debug_tr16():
     out = torch.empty(256, device="cuda", dtype=torch.float32)
     check(load().univst_debug_tr16(ptr(out), stream_ptr()), "debug_tr16")
     return out
+
+
+def delay_us(us: float):
+    check(load().univst_debug_delay_us(float(us), stream_ptr()), "debug_delay_us")
 
 
 PROFILE_CLASSES = ("gemm_big_kernel<0>", "gemm_big_kernel<1>", "gemm_kernel<*,0>", "gemm_kernel<*,1>", "attn_pp40_kernel<true>",

@@ -330,6 +330,7 @@ int univst_mask_resize(const uint8_t* mask, void* out, int F, int Hh, int W, int
     return uv_launch_mask_resize(mask, HM(out), F, Hh, W, h, w, S(s));
 }
 int univst_debug_tr16(float* out, void* s) { return uv_launch_tr16_probe(out, S(s)); }
+int univst_debug_delay_us(double us, void* s) { return uv_launch_delay_us(us, S(s)); }
 int univst_profile_enable(int on) {
     uv_prof_enable(on);
     return UV_OK;

@@ -303,3 +303,19 @@ int uv_comm_world(const univst_comm* c) { return c->world; }
 void uv_comm_bind_stream(univst_comm* c, hipStream_t s) { c->stream = s; }
 unsigned uv_comm_kv_parity(const univst_comm* c) { return (c->kv_epoch + 1) & 1; }
 int uv_comm_poll(univst_comm* c) { return comm_check(c); }
+
+
+// bench.py --emulate-wire: a kernel that occupies its stream for `us` microseconds (constant 100 MHz clock), standing in for a transfer of
+// bytes / rate on a link this 1-GPU box does not have
+namespace {
+__global__ void delay_kernel(long ticks) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+int uv_launch_delay_us(double us, hipStream_t s) {
+    UV_REQUIRE(us >= 0.0 && us < 5e6, "delay: %f us", us);
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, s, (long)(us * 100.0));
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}

@@ -173,6 +173,7 @@ int uv_launch_warp_accumulate(const uint8_t* key, const uint8_t* now, const floa
                               float thr, hipStream_t s);
 int uv_launch_warp_window_key(uint8_t* est, const float* const* flows, int nn, int F, int H, int W, int key, int r, float thr, hipStream_t s);
 int uv_launch_latent_window_smooth(half_t* x0, const float* lflow, int C, int F, int h, int w, int r, float thr, hipStream_t s);
+int uv_launch_delay_us(double us, hipStream_t s);
 int uv_launch_accumulate_u8(const uint8_t* f, float* acc, long n, hipStream_t s);
 int uv_launch_window_store(const float* acc, float weight, uint8_t* dst, long n, hipStream_t s);
 

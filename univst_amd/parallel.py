@@ -560,17 +560,30 @@ class NullComm:
     runs exactly the kernels, pack/unpack copies and host callbacks of rank r of a w-GPU job — everything except the wire.
     Results are meaningless (nothing is exchanged); only the timing is used."""
 
-    def __init__(self, rank, world):
+    def __init__(self, rank, world, wire_gbps=None, latency_us=3.0):
+        """wire_gbps (``bench.py --emulate-wire``): per-direction rate of ONE xGMI link; every exchange then occupies the stream for the time its
+        slowest transfer would take, in place — the serial issue order of csrc/comm.hip (pack -> multicast -> raise -> wait on the compute stream).
+        The first-frame pack reaches every rank over its own link from rank 0 and the halo pack over the link from rank - 1: one pack per link,
+        except on rank 1, whose single link from rank 0 carries both; each GroupNorm all-reduce costs one flag round trip (latency_us)."""
         self.rank, self.world = rank, world
+        self.wire_gbps, self.latency_us = wire_gbps, latency_us
+        self.wire_us = 0.0            # modelled wire time accumulated since the last reset (bench.py reports it per step)
+
+    def _delay(self, us):
+        if self.wire_gbps:
+            self.wire_us += us
+            _native.delay_us(us)
 
     def all_reduce_sum(self, t):
-        pass
+        self._delay(self.latency_us)
 
     def all_gather(self, t):
         return [t for _ in range(self.world)]
 
     def halo_and_broadcast(self, send_last, first, recv_prev, recv_first):
-        pass
+        if self.wire_gbps and self.world > 1:
+            packs = 2 if self.rank == 1 else 1
+            self._delay(self.latency_us + packs * send_last.numel() * send_last.element_size() / (self.wire_gbps * 1e3))
 
 
 class ThreadLoopbackComm:
