@@ -4,11 +4,28 @@ max(flops / 1 200 TF, bytes / 5 TB/s).
 
     rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile
     python tools/step_shapes.py gpurun_out/trace 12 [filter-regex]        # 12 = steps + warmup
+    python tools/step_shapes.py gpurun_out/trace seq 'conv_patch_kernel<3>' 1024   # launch-by-launch durations of one (kernel, grid) in start order (last 2 steps)
 """
 import collections, csv, glob, re, sys
 
 
+def seq():
+    root, pat, grid = sys.argv[1], re.compile(re.escape(sys.argv[3])), int(sys.argv[4])
+    rows = []
+    for f in glob.glob(root + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if pat.search(r["Kernel_Name"]) and int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1) == grid:
+                rows.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    rows.sort()
+    per = int(sys.argv[5]) if len(sys.argv) > 5 else 11
+    tail = rows[-2 * per:]
+    print(f"{len(rows)} launches; the last {len(tail)} in start order (us):")
+    print(" ".join(f"{d:.0f}" for _, d in tail))
+
+
 def main():
+    if sys.argv[2] == "seq":
+        return seq()
     root, steps = sys.argv[1], float(sys.argv[2])
     flt = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
     files = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)

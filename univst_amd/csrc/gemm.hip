@@ -1549,7 +1549,11 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
         const int ntn_c = (p.N + 319) / 320;
         const long n256 = (long)((p.M + 255) / 256) * ntn_c, n192 = (long)((p.M + 191) / 192) * ntn_c;
         // per-row cost of the 192-row tile relative to the 256-row one, measured at equal round counts: convs 0.96-1.0, linears 1.02-1.07
-        const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * (mode == 1 ? 0.99 : 1.05);
+        // (round 5: the conv factor was 0.99, which at the 64x64 level — 768 tiles of 256 rows = 3 full rounds against 1 024 of 192 = 4 — picked 192
+        // by a hair; measured on the LDS-patch kernel the 256-row tile is 2.5 - 4 % faster there (0.357 / 0.936 / 0.585 ms against 0.366 / 0.973 /
+        // 0.609 for 320->320, 960->320, 640->320 at 64 x 64), while the 32x32 and 16x16 levels keep 192: fewer rounds.  UNIVST_CONV_192_COST: A/B aid)
+        static const double conv192 = getenv("UNIVST_CONV_192_COST") ? atof(getenv("UNIVST_CONV_192_COST")) : 1.03;
+        const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * (mode == 1 ? conv192 : 1.05);
         // (the MM-DiT epilogue instantiation fits the 256-VGPR budget only with the 192-row tile: 223 registers; 256 rows spill 48)
         const bool mmdit_epi = mode == 0 && (p.act || p.gate);
         const bool use192 = mmdit_epi ? true : (bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150));
