@@ -9,7 +9,7 @@
 
 void uv_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 const char* uv_get_error() { return ""; }
-void uv_prof_begin(int, double, double, hipStream_t) {}
+void uv_prof_begin(int, double, double, hipStream_t, const char*) {}
 void uv_prof_end(hipStream_t) {}
 
 __global__ void fill(half_t* p, long n, unsigned seed, float scale) {

@@ -86,17 +86,20 @@ __global__ __launch_bounds__(256) void kv_frag_pack_kernel(const half_t* __restr
     }
 }
 
-template <int C, int D, bool LNF>
-__global__ __launch_bounds__(256, 2) void attn2_fused_kernel(Attn2Params p) {
+// OCC: resident blocks per CU the register budget is set for (2: 256 VGPRs, weight ring three k steps deep; 3: 168 VGPRs, ring two deep).  The tile is
+// the only LDS object (40 KB at C = 320: the row-statistics scratch reuses it once every thread holds its output chunks), so LDS allows either.
+template <int C, int D, bool LNF, int OCC = 2>
+__global__ __launch_bounds__(256, OCC) void attn2_fused_kernel(Attn2Params p) {
     constexpr int BM = 64, NKT = C / 64, KSTEPS = C / 32, NFW = C / 64;       // NFW: 16-column fragments per wave (C/4 columns)
     constexpr int KS = (D + 31) / 32, DV16 = (D + 15) / 16, NKF = 5;
     constexpr int KVF = (NKF * KS + DV16 * 3) * 64 * 8;                       // halfs per (branch, head) in kvf
     constexpr int CH = C / 8;                                                 // 16-byte chunks per row
     constexpr int TILE = BM * C;
     static_assert((C / 4) % D == 0 && (C / 4) / D == 2, "a wave owns two whole heads");
-    __shared__ __attribute__((aligned(16))) half_t smem[TILE + BM * CH * 4];  // tile + the float2 scratch of the row statistics
+    constexpr int RING = OCC >= 3 ? 2 : 3;                                    // weight fragments in flight: RING k steps
+    __shared__ __attribute__((aligned(16))) half_t smem[TILE];
     half_t* const T = smem;
-    float2* const scr = reinterpret_cast<float2*>(smem + TILE);
+    float2* const scr = reinterpret_cast<float2*>(smem);                      // row-statistics scratch: the tile, after the last read of it (BM * CH float2 = half the tile)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
@@ -123,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fused_kernel(Attn2Params p) {
     f4 acc[NFW][4];
     auto project = [&](const half_t* Wf, bool wait_tile, int tslot) {
         const h8* wp = reinterpret_cast<const h8*>(Wf) + (long)(wave * NFW) * KSTEPS * 64 + lane;
-        h8 a[3][NFW];
+        h8 a[RING][NFW];
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < RING - 1; ++s)
 #pragma unroll
             for (int i = 0; i < NFW; ++i) a[s][i] = wp[(long)(i * KSTEPS + s) * 64];
 #pragma unroll
@@ -136,9 +139,9 @@ __global__ __launch_bounds__(256, 2) void attn2_fused_kernel(Attn2Params p) {
         A2T(tslot);
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            if (ks + 2 < KSTEPS) {
+            if (ks + RING - 1 < KSTEPS) {
 #pragma unroll
-                for (int i = 0; i < NFW; ++i) a[(ks + 2) % 3][i] = wp[(long)(i * KSTEPS + ks + 2) * 64];
+                for (int i = 0; i < NFW; ++i) a[(ks + RING - 1) % RING][i] = wp[(long)(i * KSTEPS + ks + RING - 1) * 64];
             }
             h8 b[4];
 #pragma unroll
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void attn2_fused_kernel(Attn2Params p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < NFW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks % 3][i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < NFW; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ks % RING][i], b[j], acc[i][j], 0, 0, 0);
         }
     };
 
@@ -316,21 +319,27 @@ __global__ __launch_bounds__(256, 2) void attn2_fused_kernel(Attn2Params p) {
         }
     }
     __syncthreads();
+    h8 yv[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int id = it * 256 + tid, row = id / CH, c8 = id - row * CH;
-        const h8 y = *reinterpret_cast<const h8*>(&T[tile_off(row, c8 * 8)]);
+        yv[it] = *reinterpret_cast<const h8*>(&T[tile_off(row, c8 * 8)]);
+    }
+    if (p.stats_out) __syncthreads();                // every thread holds its chunks: the tile may become the statistics scratch
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int id = it * 256 + tid, row = id / CH, c8 = id - row * CH;
         h8 o;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            o[r] = (half_t)((float)y[r] + (float)res[it][r]);
+            o[r] = (half_t)((float)yv[it][r] + (float)res[it][r]);
             const float t = (float)o[r];
             s1 += t;
             s2 = fmaf(t, t, s2);
         }
         if (m0 + row < p.M) *reinterpret_cast<h8*>(p.Y + (long)(m0 + row) * p.ldy + c8 * 8) = o;
-        scr[id] = float2{s1, s2};
+        if (p.stats_out) scr[id] = float2{s1, s2};
     }
     A2T(7);
     if (p.stats_out) {                               // (sum, sumsq) of the stored values per row and 160-column slot, fixed order
@@ -391,6 +400,9 @@ int uv_launch_attn2_fused(const Attn2Params& p, int C, hipStream_t s) {
     const double fl = 4.0 * p.M * (double)C * C + 4.0 * p.M * (double)p.Nkv * C;
     uv_prof_begin(UV_CLS_ATTN2_FUSED, fl, 2.0 * (3.0 * p.M * C + 2.0 * C * C), s);
     const dim3 grid((p.M + 63) / 64);
+    // (measured and not instantiated: OCC = 3 — three resident blocks per CU at 168 VGPRs, weight ring two deep — 0.190 against 0.182 ms: every phase
+    // of a block gets slower (phase A 7.7 k -> 14.6 k cycles per wave), i.e. the kernel is bound by what the blocks of a CU share — weight delivery
+    // out of L2, the LDS port, the VALU port of phase B — not by latency a third block could hide)
     if (p.ln_stats) hipLaunchKernelGGL((attn2_fused_kernel<320, 40, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn2_fused_kernel<320, 40, false>), grid, dim3(256), 0, s, p);
     uv_prof_end(s);
