@@ -30,7 +30,10 @@ for lvl, (M, C, nblk) in enumerate([(196608, 320, 5), (49152, 640, 5), (12288, 1
         ms = t(lambda: _native.linear(x, w, bias=b, residual=r, geglu=geglu, out=out))
         fl = 2.0 * M * N * K
         by = 2.0 * (M * K + N * K + M * (N // 2 if geglu else N) * (2 if res else 1))
-        line = f"L{lvl} {tag:11s} M={M:6d} N={N:5d} K={K:4d} x{cnt * nblk:2d}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF {by / ms / 1e6:7.1f} GB/s"
+        bound = max(fl / 1200e12, by / 5e12) * 1e3          # ms: what the shape costs at 1 200 TFLOP/s (the plateau of every MFMA kernel here) or 5 TB/s, whichever binds
+        line = f"L{lvl} {tag:11s} M={M:6d} N={N:5d} K={K:4d} x{cnt * nblk:2d}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF {by / ms / 1e6:7.1f} GB/s | bound {bound:6.3f} ms ({'flops' if fl / 1200e12 > by / 5e12 else 'bytes'}) x{ms / bound:4.2f}"
+        totb = globals().get("totb", 0.0) + bound * cnt * nblk
+        globals()["totb"] = totb
         tot += ms * cnt * nblk
         if vendor:
             outv = torch.empty(M, N, device="cuda", dtype=torch.float16)
@@ -42,4 +45,5 @@ for lvl, (M, C, nblk) in enumerate([(196608, 320, 5), (49152, 640, 5), (12288, 1
             line += f" | vendor {mv:7.3f} ms {fl / mv / 1e9:7.1f} TF"
         print(line, flush=True)
         del x, w, b, r, out
+print(f"sum of max(flops / 1 200 TF, bytes / 5 TB/s) over the same launches: {globals().get('totb', 0.0):.2f} ms")
 print(f"sum over a step: {tot:.2f} ms" + (f" | vendor (no geglu / bias fusion) {totv:.2f} ms" if vendor else ""))
