@@ -22,6 +22,17 @@ python bench.py --frames 32 --emulate-rank 0/8 --no-cpu-baseline > $O/round${ROU
 python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 7/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank7of8.json 2>> $O/raw/bench.err
 python bench.py --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8.json 2>> $O/raw/bench.err
+# the same ranks with the wire modelled (round 5): every exchange keeps the stream busy for pack bytes / 64 GB/s per link, serial as comm.hip issues them
+python bench.py --emulate-rank 1/8 --emulate-wire 64 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8_wire64.json 2>> $O/raw/bench.err
+python bench.py --frames 32 --emulate-rank 1/8 --emulate-wire 64 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8_wire64.json 2>> $O/raw/bench.err
+python bench.py --workload vae_decode > $O/round${ROUND}_bench_vae_decode.json 2>> $O/raw/bench.err
+# the linears of a step by shape, each next to max(flops / 1 200 TF, bytes / 5 TB/s); the fused text cross-attention against the three launches it replaces
+python tools/bench_linears_step.py > $O/round${ROUND}_linears_by_shape.txt 2>> $O/raw/bench.err
+python tools/bench_attn2.py > $O/round${ROUND}_attn2_fused_vs_three_launches.txt 2>> $O/raw/bench.err
+tools/probes/attn2_probe > $O/round${ROUND}_attn2_probe.txt 2>&1
+# per-shape table of the step in situ (kernel symbol x grid size)
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-profile --no-skip-dead-branches-leg > $O/raw/trace.log 2>&1
+python tools/step_shapes.py $O/raw/trace 12 > $O/round${ROUND}_step_shapes.txt 2>&1
 # is the per-rank step launch-bound?  kernel-time sum (rocprofv3) against the wall time of the same run: no gaps -> a hipGraph has nothing to remove
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/raw/stats_emu -- python bench.py --emulate-rank 1/8 --steps 50 --warmup 2 --no-cpu-baseline --no-profile > $O/raw/emu_rocprof.json 2>> $O/raw/bench.err
 python - <<PY > $O/round${ROUND}_emulated_rank_kernel_sum.txt

@@ -246,7 +246,8 @@ class FrameShard:
         err = once()
         kind = type(self.comm).__name__
         self.report = {"comm": kind, "max_rel_err_vs_unsharded": err}
-        if not err < tol:
+        force = os.environ.get("UNIVST_SHARD_REJECT_FIRST") == "1"       # test aid: walk the fall-back (collective close of the rejected communicator) on a healthy box
+        if force or not err < tol:
             if self.rank == 0:
                 print(f"[univst_amd] frame-sharded forward through {kind} differs from the unsharded one (max rel err {err}); "
                       "switching to the torch.distributed callbacks", flush=True)
