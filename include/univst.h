@@ -125,6 +125,8 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
  *             intermediates stay in the 256 MB Infinity Cache: 0 = auto (bands of >= 65 536 rows), n = n bands.  Same results up to fp32
  *             summation order (a band may take another tile than the full tensor).  An
  *             experiment kept as a switch: -13 % on the isolated chain (tools/bench_mall_bands.py), +0.4 ms per step in the graph.
+ *   "gn_fold" (default 1, env UNIVST_GN_FOLD): the per-frame GroupNorm in front of a transformer block (attention.py:121) is folded into proj_in as per-frame
+ *             weight sets + an fp32 bias where the copies are cheap against the apply pass they replace (the 64x64 level); 0: always the apply pass.
  *   "attn2_fused" (default 1, env UNIVST_ATTN2_FUSED=0 disables it library-wide): the text cross-attention of a transformer block (attention.py:321-327)
  *             as one launch (univst_attn2_fused) where the level's shape is served, instead of q projection + attention + out projection. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
@@ -218,6 +220,15 @@ int univst_conv_nhwc_tapinner(const void* X1, const void* X2, int C1, int C2, in
 int univst_conv3x3_patch(const void* X1, const void* X2, int C1, int C2, int imgs, int Hs, int Ws, int upsample, const void* W32,
                          const void* bias, const void* rowbias, int rows_per_rowbias, const void* residual, void* Y, int Cout,
                          void* stream);
+/* A GroupNorm folded into the linear that consumes its output (the per-frame GroupNorm -> proj_in of a transformer block, attention.py:121-123): per
+ * statistics unit s (rows_per_stat rows) the weight set W_sets[s][n][k] = fp16(W[n][k] * gamma_k * rstd_{s,g(k)}) and the fp32 bias
+ * bias32[s][n] = bias[n] + sum_k W[n][k] * (beta_k - mean_{s,g(k)} * rstd * gamma_k); univst_linear_sets then runs on the RAW rows with the set of each
+ * row range (rows_per_set = rows_per_stat: a multiple of 256 or 192) — GroupNorm(X) W^T + bias without the normalised copy of X.  stats_out as in
+ * univst_linear_ln.  Direct 256x320 problems only (N % 320 == 0, >= 150 tiles); else UNIVST_ERR_ARG. */
+int univst_groupnorm_fold_linear(const void* X, int C, int64_t rows, int rows_per_stat, int groups, float eps, const void* gamma, const void* beta,
+                                 const void* W, const void* bias, int N, void* W_sets, float* bias32, void* workspace, void* stream);
+int univst_linear_sets(const void* X, int64_t ldx, const void* W_sets, const float* bias32, int rows_per_set, const void* residual, int64_t ldr,
+                       void* Y, int64_t ldy, int M, int N, int K, float* stats_out, void* stream);
 /* GroupNorm(+SiLU) on NHWC rows; rows_per_stat = F*H*W (5-D, stats across frames: resnet.py:338,369) or H*W
  * (per frame: attention.py:121).  workspace: univst_groupnorm_workspace_bytes(). */
 int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups);

@@ -130,3 +130,38 @@ def test_attn2_fused_rejects_other_shapes(nat):
     w = torch.zeros(320, 320).half().cuda()
     with pytest.raises(RuntimeError, match="not a shape this kernel serves"):
         nat.attn2_fused(x, w, torch.zeros(2 * 77, 640).half().cuda(), w, None, 48, 8)       # a block would straddle two branches
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# the transformer block's per-frame GroupNorm folded into proj_in (attention.py:121-123)
+
+@pytest.mark.parametrize("frames,N,mean", [(12, 4096, 0.5), (12, 4096, 25.0), (64, 768, 0.5)])        # 256-row tiles inside a frame; 768 rows per frame: 192-row tiles
+def test_groupnorm_folded_into_linear(nat, frames, N, mean):
+    """univst_groupnorm_fold_linear + univst_linear_sets against torch fp32 GroupNorm(32, eps 1e-6, per frame) -> linear on the same fp16 inputs; the
+    second case has group means of 25 standard deviations (the folded bias is fp32: an fp16 one would lose 1 % of the output scale there)."""
+    C = 320
+    g = torch.Generator().manual_seed(frames + N)
+    x = (torch.randn(frames * N, C, generator=g) * (1.0 + torch.rand(C, generator=g)) + mean * torch.randn(C, generator=g)).half().cuda()
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).half().cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).half().cuda()
+    w = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    b = (0.1 * torch.randn(C, generator=g)).half().cuda()
+    wsets, b32 = nat.groupnorm_fold_linear(x, gamma, beta, 32, 1e-6, N, w, b)
+    stats = torch.full((frames * N, 2, 2), float("nan"), device="cuda")
+    got = nat.linear_sets(x, wsets, b32, N, stats_out=stats).float()
+    xn = F.group_norm(x.float().view(frames, N, C).transpose(1, 2), 32, gamma.float(), beta.float(), 1e-6).transpose(1, 2).reshape(frames * N, C)
+    ref = xn @ w.float().t() + b.float()
+    scale = ref.abs().max().item()
+    mx = (got - ref).abs().max().item() / scale
+    rms = ((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert mx < 3e-3 and rms < 1e-3, (mx, rms)
+    two = nat.linear(nat.groupnorm_nhwc(x.view(frames, N, 1, C), gamma, beta, 32, 1e-6, N).view(frames * N, C), w, bias=b).float()
+    assert (got - two).abs().max().item() / scale < 3e-3
+    want_st = torch.stack([got.view(-1, 2, 160).sum(-1), (got * got).view(-1, 2, 160).sum(-1)], -1)
+    assert torch.allclose(stats, want_st, rtol=2e-5, atol=2e-3)
+
+
+def test_linear_sets_refuses_what_the_direct_path_does_not_take(nat):
+    x = torch.zeros(1536, 320).half().cuda()
+    with pytest.raises(RuntimeError, match="direct 256x320 path"):
+        nat.linear_sets(x, torch.zeros(2, 320, 320).half().cuda(), torch.zeros(2, 320, device="cuda"), 768)

@@ -83,6 +83,8 @@ SIGNATURES = {
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv3x3_patch": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
+    "univst_groupnorm_fold_linear": (_I, [_P, _I, _L, _I, _I, _F, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "univst_linear_sets": (_I, [_P, _L, _P, _P, _I, _P, _L, _P, _L, _I, _I, _I, _P, _P]),
     "univst_groupnorm_workspace_bytes": (_L, [_L, _I, _I]),
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
@@ -292,6 +294,28 @@ def conv3x3_patch(x1, w_t32, bias=None, x2=None, rowbias=None, rows_per_rowbias=
     out = torch.empty(imgs, He, We, Cout, device=x1.device, dtype=torch.float16)
     check(load().univst_conv3x3_patch(ptr(x1), ptr(x2), C1, C2, imgs, Hs, Ws, int(upsample), ptr(w_t32), ptr(bias), ptr(rowbias), rows_per_rowbias,
                                       ptr(residual), ptr(out), Cout, stream_ptr()), "conv3x3_patch")
+    return out
+
+
+def groupnorm_fold_linear(x, gamma, beta, groups, eps, rows_per_stat, w, bias=None):
+    """-> (W_sets [S, N, C] fp16, bias32 [S, N] fp32): the GroupNorm of x [rows, C] folded into the linear (w [N, C], bias) that consumes it."""
+    _f16(x), _f16(w)
+    rows, C_ = x.shape
+    S, N = rows // rows_per_stat, w.shape[0]
+    ws = torch.empty(max(1, load().univst_groupnorm_workspace_bytes(rows, rows_per_stat, groups) // 4), device=x.device, dtype=torch.float32)
+    wsets = torch.empty(S, N, C_, device=x.device, dtype=torch.float16)
+    b32 = torch.empty(S, N, device=x.device, dtype=torch.float32)
+    check(load().univst_groupnorm_fold_linear(ptr(x), C_, rows, rows_per_stat, groups, eps, ptr(gamma), ptr(beta), ptr(w), ptr(bias), N, ptr(wsets), ptr(b32),
+                                              ptr(ws), stream_ptr()), "groupnorm_fold_linear")
+    return wsets, b32
+
+
+def linear_sets(x, wsets, bias32, rows_per_set, residual=None, stats_out=None):
+    _f16(x), _f16(wsets)
+    M, K = x.shape
+    N = wsets.shape[1]
+    out = torch.empty(M, N, device=x.device, dtype=torch.float16)
+    check(load().univst_linear_sets(ptr(x), K, ptr(wsets), ptr(bias32), rows_per_set, ptr(residual), N, ptr(out), N, M, N, K, ptr(stats_out), stream_ptr()), "linear_sets")
     return out
 
 

@@ -57,6 +57,7 @@ int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     h->impl.cfg = *cfg;
     if (const char* e = getenv("UNIVST_LN_FOLD")) h->impl.ln_fold = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("UNIVST_GN_PRODUCER")) h->impl.gn_producer = atoi(e) != 0;
+    if (const char* e = getenv("UNIVST_GN_FOLD")) h->impl.gn_fold = atoi(e) != 0;
     if (const char* e = getenv("UNIVST_CHAIN_BANDS")) h->impl.chain_bands = atoi(e) < 0 ? 0 : atoi(e);
     *out = h;
     return UV_OK;
@@ -66,6 +67,10 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value) {
     if (!strcmp(name, "ln_fold")) {
         UV_REQUIRE(value >= 0 && value <= 2, "unet_set_option: ln_fold is 0, 1 or 2");
         h->impl.ln_fold = value;
+        return UV_OK;
+    }
+    if (!strcmp(name, "gn_fold")) {
+        h->impl.gn_fold = value != 0;
         return UV_OK;
     }
     if (!strcmp(name, "attn2_fused")) {
@@ -271,6 +276,22 @@ int univst_conv3x3_patch(const void* X1, const void* X2, int C1, int C2, int img
     g.bias = H(bias); g.rowbias = H(rowbias); g.rows_per_rb = rows_per_rb > 0 ? rows_per_rb : 1;
     g.R = H(R); g.ldr = Cout; g.Y = HM(Y); g.ldy = Cout;
     return uv_launch_gemm(g, 1, S(s));
+}
+int univst_groupnorm_fold_linear(const void* X, int C, int64_t rows, int rows_per_stat, int groups, float eps, const void* gamma, const void* beta,
+                                 const void* W, const void* bias, int N, void* W_sets, float* bias32, void* ws, void* s) {
+    UV_REQUIRE(X && gamma && beta && W && W_sets && bias32 && ws && N > 0, "groupnorm_fold_linear: null argument");
+    UvGnFold f;
+    f.W = H(W); f.bias = H(bias); f.N = N; f.W_out = HM(W_sets); f.bias32 = bias32;
+    return uv_launch_groupnorm(H(X), nullptr, C, 0, rows, rows_per_stat, groups, eps, H(gamma), H(beta), 0, nullptr, (float*)ws, S(s), nullptr, nullptr, nullptr, &f);
+}
+int univst_linear_sets(const void* X, int64_t ldx, const void* W_sets, const float* bias32, int rows_per_set, const void* R, int64_t ldr, void* Y, int64_t ldy,
+                       int M, int N, int K, float* stats_out, void* s) {
+    UV_REQUIRE(X && W_sets && bias32 && Y && rows_per_set > 0, "linear_sets: null argument");
+    GemmParams g;
+    g.X = H(X); g.ldx = ldx; g.W = H(W_sets); g.bias32 = bias32; g.w_rows_per_set = rows_per_set;
+    g.R = H(R); g.ldr = ldr; g.Y = HM(Y); g.ldy = ldy; g.M = M; g.N = N; g.K = K; g.stats_out = stats_out;
+    UV_REQUIRE(uv_linear_takes_big_direct(M, N, K, ldx), "linear_sets: M=%d N=%d K=%d is not a problem the direct 256x320 path takes (N %% 320 == 0, >= 150 tiles)", M, N, K);
+    return uv_launch_gemm(g, 0, S(s));
 }
 int64_t univst_groupnorm_workspace_bytes(int64_t rows, int rows_per_stat, int groups) {
     if (rows_per_stat <= 0) return 0;

@@ -44,6 +44,7 @@ __device__ __forceinline__ void epi_const_stage(const GemmParams& p, int m0, int
         const bool ok = n < p.N;
         hb[tid] = (p.bias && ok) ? p.bias[n] : (half_t)0.f;
         hb[320 + tid] = (p.bias2 && ok) ? p.bias2[n] : (half_t)0.f;
+        if (LNF != 2) epc[EPC_LNB + tid] = (p.bias32 && ok) ? p.bias32[(long)(p.w_rows_per_set ? m0 / p.w_rows_per_set : 0) * p.N + n] : 0.f;      // fp32 bias of the tile's weight set
         if (LNF == 2) {
             epc[tid] = ok ? p.ln_wsum[n] : 0.f;
             epc[EPC_LNB + tid] = ok ? p.ln_bias[n] : 0.f;
@@ -298,6 +299,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, const f4 
                     const h8 bv = *reinterpret_cast<const h8*>(hb + c);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += (float)bv[r];
+                }
+                if (LNF != 2 && p.bias32) {
+                    const f4 b0 = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + c), b1 = *reinterpret_cast<const f4*>(cf + EPC_LNB + cn + c + 4);
+                    v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
+                    v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
                 }
                 if (p.rowbias) {
                     const h8 bv = hoist_rb ? rres[it] : *reinterpret_cast<const h8*>(p.rowbias + (long)(m / p.rows_per_rb) * (p.ldrb ? p.ldrb : p.N) + n);
@@ -1016,11 +1022,12 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(GemmParams p) {
     }
     unsigned woff[5];
     bool w_ok[5];
+    const long wset = (MODE == 0 && p.w_rows_per_set) ? (long)(m0 / p.w_rows_per_set) * p.N * p.K : 0;      // this tile's weight set (GemmParams::w_rows_per_set)
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
         int n = n0 + rb + 64 * i;
         w_ok[i] = n < p.N;
-        woff[i] = (unsigned)((long)n * p.K + kc * 8);
+        woff[i] = (unsigned)(wset + (long)n * p.K + kc * 8);
     }
     const int Cin = p.C1 + p.C2;
     int tap = 0, cc = kc * 8;
@@ -1556,7 +1563,13 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
         const double c256 = (double)((n256 + ncu - 1) / ncu) * 256.0, c192 = (double)((n192 + ncu - 1) / ncu) * 192.0 * (mode == 1 ? conv192 : 1.05);
         // (the MM-DiT epilogue instantiation fits the 256-VGPR budget only with the 192-row tile: 223 registers; 256 rows spill 48)
         const bool mmdit_epi = mode == 0 && (p.act || p.gate);
-        const bool use192 = mmdit_epi ? true : (bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150));
+        bool use192 = mmdit_epi ? true : (bm_env ? bm_env == 192 : (c192 < c256 && n192 >= 150));
+        if (p.w_rows_per_set) {           // weight sets per row range: a tile must lie inside one set
+            UV_REQUIRE(mode == 0 && p.bias32 && !p.geglu && !p.ln_stats && !mmdit_epi && p.M % p.w_rows_per_set == 0 && (p.w_rows_per_set % 256 == 0 || p.w_rows_per_set % 192 == 0) &&
+                       (long)(p.M / p.w_rows_per_set) * p.N * p.K + (long)p.N * p.K < (1L << 31),
+                       "linear: weight sets need a plain linear, an fp32 bias per set and %d rows per set that a 256- or 192-row tile divides", p.w_rows_per_set);
+            if (p.w_rows_per_set % (use192 ? 192 : 256) != 0) use192 = !use192;
+        }
         const long nblk = use192 ? n192 : n256;
         const long xmax = (mode == 0) ? (long)p.M * p.ldx : (long)p.M * (p.C1 > p.C2 ? p.C1 : p.C2) * 4;
         const long bigmin = big_env().bigmin;
@@ -1620,6 +1633,7 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
                     own_ws = true;
                 }
             }
+            UV_REQUIRE(!p.w_rows_per_set || (q.epi_lds == 1 && q.splits == 1), "linear: weight sets run on the direct 256x320 path with the LDS epilogue only");
             if (p.gn_out) {       // GroupNorm statistics from this epilogue: LDS epilogue, whole 160-column halves of 10 / 20 / 40-channel groups, no split-K
                 const bool ok = q.epi_lds == 1 && q.splits == 1 && !p.geglu && !p.stats_out && !p.act && !p.gate && p.N % 320 == 0 && p.M % 16 == 0 &&
                                 p.gn_G > 0 && p.gn_gw * p.gn_G == p.N && (p.gn_gw == 10 || p.gn_gw == 20 || p.gn_gw == 40);
@@ -1674,6 +1688,7 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
             return UV_OK;
         }
     }
+    UV_REQUIRE(!p.w_rows_per_set && !p.bias32, "linear: weight sets / an fp32 bias exist on the direct 256x320 path only (M=%d N=%d K=%d does not take it)", p.M, p.N, p.K);
     const SmallPlan plan = small_plan(p.M, p.N, p.K, p.geglu != 0, mode, p.stats_out != nullptr);
     if (lnf) {
         UV_REQUIRE(mode == 0 && !p.geglu && !p.act && !p.gate && plan.splits == 1 && !(p.ln_stats && p.stats_out) &&

@@ -56,6 +56,12 @@ struct GemmParams {
     float* gn_out = nullptr;
     int gn_G = 0, gn_gw = 0;
     int* gn_emitted = nullptr;
+    // per-row-range WEIGHT SETS (round 5: the transformer's per-frame GroupNorm folded into proj_in, uv_launch_groupnorm's `fold`): rows
+    // [s * w_rows_per_set, (s + 1) * w_rows_per_set) use W + s * N * K and, in place of `bias`, bias32 + s * N (fp32: it carries sum_k W[n][k] *
+    // (beta_k - mean * rstd * gamma_k), which cancels against the scaled activations when a group's mean is many standard deviations).  Direct
+    // 256x320 linears whose tile height divides w_rows_per_set only.
+    int w_rows_per_set = 0;
+    const float* bias32 = nullptr;
     float* stats_out = nullptr;
     const float* ln_stats = nullptr;
     int ln_slots = 0;
@@ -142,9 +148,19 @@ struct UvGnComm {      // cross-rank reduction hook of the 5-D GroupNorm (frame 
 int uv_groupnorm_workspace_floats(int S, int G);
 // pre_part / pre_part2: statistics already emitted by the producers of s1 / s2 (GemmParams::gn_out, [C/10][rows/16][2] each: 10-channel
 // sub-groups): the partial-sum pass over the tensor(s) is skipped when every source has them
+// fold (round 5): instead of applying the normalisation, fold it into the linear that consumes the tensor — per stat unit s (a frame) the weight
+// set W_s[n][k] = fp16(W[n][k] * gamma_k * rstd_{s,g(k)}) and the fp32 bias b_s[n] = bias[n] + sum_k W[n][k] * (beta_k - mean_{s,g(k)} * rstd * gamma_k):
+// the linear then runs on the RAW tensor (GemmParams::w_rows_per_set / bias32) and the apply pass (read + write of the tensor) disappears.  `out` unused.
+struct UvGnFold {
+    const half_t* W = nullptr;       // [N][C] the consuming linear's weight
+    const half_t* bias = nullptr;    // [N] or null
+    int N = 0;
+    half_t* W_out = nullptr;         // [S][N][C]
+    float* bias32 = nullptr;         // [S][N]
+};
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G, float eps,
                         const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part, hipStream_t stream,
-                        const UvGnComm* comm = nullptr, const float* pre_part = nullptr, const float* pre_part2 = nullptr);
+                        const UvGnComm* comm = nullptr, const float* pre_part = nullptr, const float* pre_part2 = nullptr, const UvGnFold* fold = nullptr);
 int uv_launch_layernorm(const half_t* x, long ldx, half_t* y, long ldy, const half_t* gamma, const half_t* beta, long rows,
                         int C, float eps, hipStream_t stream);
 int uv_launch_attention(const AttnParams& p, hipStream_t stream);

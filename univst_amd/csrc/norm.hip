@@ -304,6 +304,38 @@ __global__ __launch_bounds__(256) void gn_reduce_sub_kernel(const float2* __rest
     }
 }
 
+// GroupNorm folded into the linear that consumes the tensor (UvGnFold): one wave per (stat unit s, output row n).  The group statistics are
+// turned into (mean, rstd) exactly as gn_apply_kernel does (double), a_k = gamma_k * rstd, b_k = beta_k - mean * a_k.
+__global__ __launch_bounds__(256) void gn_fold_linear_kernel(const float* __restrict__ red, const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                             int G, int C, long count_rows, float eps, const half_t* __restrict__ W,
+                                                             const half_t* __restrict__ bias, int N, half_t* __restrict__ Wout, float* __restrict__ bias32) {
+    extern __shared__ float sm[];                    // [G] mean, [G] rstd of this unit
+    const int s = blockIdx.y, cpg = C / G;
+    for (int gi = threadIdx.x; gi < G; gi += 256) {
+        const double a = red[((long)s * G + gi) * 2], b = red[((long)s * G + gi) * 2 + 1];
+        const double cnt = (double)count_rows * cpg;
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sm[gi] = (float)mean;
+        sm[G + gi] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = lane; k < C; k += 64) {
+        const int gi = k / cpg;
+        const float w = (float)W[(long)n * C + k];
+        const float ak = (float)gamma[k] * sm[G + gi];
+        const float bk = (float)beta[k] - sm[gi] * ak;
+        Wout[((long)s * N + n) * C + k] = (half_t)(w * ak);
+        acc = fmaf(w, bk, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) bias32[(long)s * N + n] = acc + (bias ? (float)bias[n] : 0.f);
+}
+
 // LayerNorm over the last dim, one wave per row, row kept in registers (two-pass variance).
 template <int MAXCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx, half_t* __restrict__ y,
@@ -385,7 +417,7 @@ int uv_groupnorm_workspace_floats(int S, int G) { return S * (GN_MAX_CHUNKS + 1)
 
 int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long rows, int rows_per_stat, int G,
                         float eps, const half_t* gamma, const half_t* beta, int silu, half_t* out, float* part,
-                        hipStream_t stream, const UvGnComm* comm, const float* pre_part, const float* pre_part2) {
+                        hipStream_t stream, const UvGnComm* comm, const float* pre_part, const float* pre_part2, const UvGnFold* fold) {
     const int C = C1 + C2;
     UV_REQUIRE(C % 8 == 0 && C1 % 8 == 0, "groupnorm: channels must be multiples of 8 (C1=%d C2=%d)", C1, C2);
     UV_REQUIRE(C % G == 0, "groupnorm: C=%d not divisible by G=%d", C, G);
@@ -397,7 +429,8 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     const bool sharded_stats = comm && comm->world > 1;
     // producer statistics are usable when every source has them and the groups are whole runs of 10-channel sub-groups
     if (pre_part && !((!s2 || pre_part2) && (C / G) % 10 == 0 && C1 % 10 == 0 && C2 % 10 == 0 && rows_per_stat % 16 == 0)) pre_part = nullptr;
-    if (!pre_part && (C / G) % 2 == 0 && C1 % 2 == 0 && rows * C * 2 <= small_bytes && (long)S * G >= 48) {
+    UV_REQUIRE(!fold || (fold->W && fold->W_out && fold->bias32 && fold->N > 0 && !s2 && !silu), "groupnorm: fold needs a weight, its outputs, one source and no SiLU");
+    if (!fold && !pre_part && (C / G) % 2 == 0 && C1 % 2 == 0 && rows * C * 2 <= small_bytes && (long)S * G >= 48) {
         uv_prof_begin(UV_CLS_GROUPNORM, 0.0, 4.0 * (double)rows * C, stream);      // one read from memory (the block's second read comes out of L2) + one write
         if (!sharded_stats) {
             hipLaunchKernelGGL((gn_small_kernel<0>), dim3(G, S), dim3(256), 0, stream, s1, s2, C1, C2, rows_per_stat, G, eps, gamma, beta, silu, out, (float*)nullptr);
@@ -439,7 +472,7 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
     const int rpc = (rows_per_stat + nchunk - 1) / nchunk;
     nchunk = (rows_per_stat + rpc - 1) / rpc;
     // what the launches below move: the apply pass reads and writes the tensor; the statistics pass reads it once more unless the producers left them
-    uv_prof_begin(UV_CLS_GROUPNORM, 0.0, (pre_part ? 4.0 : 6.0) * (double)rows * C, stream);
+    uv_prof_begin(UV_CLS_GROUPNORM, 0.0, ((pre_part ? 0.0 : 2.0) + (fold ? 0.0 : 4.0)) * (double)rows * C, stream);
     size_t lds1 = (size_t)3 * TR * C * sizeof(float);
     UV_REQUIRE(lds1 <= 160 * 1024, "groupnorm: LDS %zu too large", lds1);
     const float* chunk_part = part;
@@ -477,6 +510,13 @@ int uv_launch_groupnorm(const half_t* s1, const half_t* s2, int C1, int C2, long
         count_rows = (long)rows_per_stat * comm->world;
     }
     const float* stats = red;
+    if (fold) {
+        hipLaunchKernelGGL(gn_fold_linear_kernel, dim3((fold->N + 3) / 4, S), dim3(256), 2 * G * sizeof(float), stream, stats, gamma, beta, G, C, count_rows, eps,
+                           fold->W, fold->bias, fold->N, fold->W_out, fold->bias32);
+        uv_prof_end(stream);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
     const int nch_apply = 1;
     hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, S), dim3(block), 2 * G * sizeof(float), stream, s1, s2, C1, C2,
                        rows_per_stat, rpb, G, nch_apply, eps, count_rows, stats, gamma, beta, silu, out);

@@ -675,7 +675,7 @@ struct Fwd {
     half_t* W(const std::string& k) { return u.W(k); }
 
     int groupnorm(const Act& a, const Act* b, int rows_per_stat, float eps, const std::string& p, int silu, half_t* out,
-                  bool cross_frame = false) {
+                  bool cross_frame = false, const UvGnFold* fold = nullptr) {
         UvGnComm gc;
         const bool sharded = cross_frame && u.world > 1;
         if (sharded) {             // 5-D GroupNorm statistics span all frames of a branch => sum the partials over ranks
@@ -687,7 +687,7 @@ struct Fwd {
         }
         return uv_launch_groupnorm(a.p, b ? b->p : nullptr, a.C, b ? b->C : 0, a.rows(), rows_per_stat, u.cfg.norm_num_groups,
                                    eps, W(p + ".weight"), W(p + ".bias"), silu, out, gn_ws, s, sharded ? &gc : nullptr,
-                                   rows_per_stat % 16 == 0 ? a.gst : nullptr, b ? b->gst : nullptr);
+                                   rows_per_stat % 16 == 0 ? a.gst : nullptr, b ? b->gst : nullptr, fold);
     }
     // want_gst: let the epilogue leave the GroupNorm statistics of the output (Act::gst) for a following GroupNorm
     int conv(const Act& a, const Act* b, const std::string& p, int Cout, int taps, int stride, int up, const half_t* rowbias,
@@ -792,8 +792,12 @@ struct Fwd {
     // ln_slots = K / 160 slots per row) into this linear: `wkey` then names the derived "#ln" weight and the bias comes with it.
     int linear(const half_t* X, long ldx, long M, int K, const std::string& wkey, const std::string& bkey, int N, half_t* Y,
                long ldy, const half_t* R = nullptr, long ldr = 0, const half_t* bias2 = nullptr, int geglu = 0, float* stats_out = nullptr,
-               const float* ln_in = nullptr, const float** gst_out = nullptr) {
+               const float* ln_in = nullptr, const float** gst_out = nullptr, const half_t* wsets = nullptr, const float* bias32 = nullptr, int rows_per_set = 0) {
         GemmParams g;
+        if (wsets) {                  // per-frame weight sets + fp32 bias (a GroupNorm folded into this linear: uv_launch_groupnorm's fold)
+            g.w_rows_per_set = rows_per_set;
+            g.bias32 = bias32;
+        }
         int emitted = 0;
         if (gst_out) {
             *gst_out = nullptr;
@@ -817,15 +821,15 @@ struct Fwd {
         g.M = (int)M;
         g.K = K;
         g.N = N;
-        g.W = W(wkey);
-        g.bias = (bkey.empty() || ln_in) ? nullptr : W(bkey);
+        g.W = wsets ? wsets : W(wkey);
+        g.bias = (bkey.empty() || ln_in || wsets) ? nullptr : W(bkey);
         g.Y = Y;
         g.ldy = ldy;
         g.R = R;
         g.ldr = ldr;
         g.bias2 = bias2;
         g.geglu = geglu;
-        if (!g.W || (!bkey.empty() && !ln_in && !g.bias)) return u.missing_error();
+        if (!g.W || (!bkey.empty() && !ln_in && !wsets && !g.bias)) return u.missing_error();
         g.partial = sk_ws;
         g.partial_bytes = UV_SPLITK_WS_BYTES;
         RUN(uv_launch_gemm(g, 0, s));
@@ -900,7 +904,25 @@ struct Fwd {
         const std::string b = p + ".transformer_blocks.0";
         half_t* t0 = alloc(rows * C);
         if (!t0) return UV_ERR_STATE;
-        RUN(groupnorm(x, nullptr, N, 1e-6f, p + ".norm", 0, t0));
+        // The block's per-frame GroupNorm (attention.py:121) folded into proj_in where that pays (round 5): per frame a weight set gamma * rstd (.) W and
+        // an fp32 bias carrying the mean term, proj_in then reads the RAW tensor — the apply pass (read + write of the tensor) goes for B*F weight copies
+        // (9.8 MB against 252 MB at the 64x64 level; at the 32x32 level the copies are a third of the pass: not taken)
+        const std::string wpi = p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight");
+        const long set_bytes = (long)x.imgs * C * C * 2, apply_bytes = rows * C * 4;
+        const bool gnf = u.gn_fold && uv_linear_takes_big_direct(rows, C, C) && (N % 256 == 0 || N % 192 == 0) && 8 * set_bytes <= apply_bytes;
+        half_t* wsets = nullptr;
+        float* b32 = nullptr;
+        if (gnf) {
+            wsets = alloc((long)x.imgs * C * C);
+            b32 = (float*)alloc((long)x.imgs * C * 2);
+            if (!wsets || !b32) return UV_ERR_STATE;
+            UvGnFold gf;
+            gf.W = W(wpi); gf.bias = W(p + ".proj_in.bias"); gf.N = C; gf.W_out = wsets; gf.bias32 = b32;
+            if (!gf.W || !gf.bias) return u.missing_error();
+            RUN(groupnorm(x, nullptr, N, 1e-6f, p + ".norm", 0, nullptr, false, &gf));
+        } else {
+            RUN(groupnorm(x, nullptr, N, 1e-6f, p + ".norm", 0, t0));
+        }
         half_t* h = alloc(rows * C);
         if (!h) return UV_ERR_STATE;
         // The three LayerNorms of the block are folded into the linears around them when all of those take the direct 256x320 path
@@ -918,8 +940,11 @@ struct Fwd {
         const bool fold3 = fold && u.ln_fold > 1 && (xres3 || uv_linear_fold_consumer_ok(rows, 8 * C, C, true)) && (fold_small > 1 || uv_linear_takes_big_direct(rows, C, C));
         float* lnst = fold ? (float*)alloc(rows * (C / 160) * 4) : nullptr;      // [rows][C/160][2] fp32
         if (fold && !lnst) return UV_ERR_STATE;
-        RUN(linear(t0, C, rows, C, p + (u.find(p + ".proj_in.weight#nhwc") ? ".proj_in.weight#nhwc" : ".proj_in.weight"), p + ".proj_in.bias", C, h, C,
-                   nullptr, 0, nullptr, 0, lnst));
+        RUN(linear(gnf ? x.p : t0, C, rows, C, wpi, p + ".proj_in.bias", C, h, C, nullptr, 0, nullptr, 0, lnst, nullptr, nullptr, wsets, b32, N));
+        if (gnf) {
+            free(wsets);
+            free(b32);
+        }
         // ---- attn1
         half_t *gm, *bt;
         gm = W(b + ".norm1.weight"); bt = W(b + ".norm1.bias");

@@ -252,11 +252,13 @@ class FrameShard:
                 print(f"[univst_amd] frame-sharded forward through {kind} differs from the unsharded one (max rel err {err}); "
                       "switching to the torch.distributed callbacks", flush=True)
             rejected = self.comm
+            unet._sync_native()                            # the UNet lets go of the rejected communicator's regions ...
+            _native.check(_native.load().univst_unet_set_comm(unet._native_handle, 0, 1, None, 0, _native.ALLREDUCE_FN(), _native.KVEXCHANGE_FN(), None),
+                          "unet_set_comm(detach)")
+            if hasattr(rejected, "close"):
+                rejected.close()                           # ... before they are unmapped, on all ranks together
             self.comm = TorchDistComm() if dist.get_backend() == "nccl" else HostStagedDistComm()
             self._handle, self._tokens, self.ws = None, 0, None
-            with self.detached(unet):                      # the UNet lets go of the rejected communicator's regions ...
-                if hasattr(rejected, "close"):
-                    rejected.close()                       # ... before they are unmapped, on all ranks together
             self.ensure(unet, xf.shape[-1] * xf.shape[-2])
             err2 = once()
             self.report = {"comm": type(self.comm).__name__, "max_rel_err_vs_unsharded": err2, "rejected": {"comm": kind, "max_rel_err": err}}
