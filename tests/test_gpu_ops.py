@@ -692,3 +692,21 @@ def test_linear_layernorm_fold_rejects_split_k_problems(nat):
     st = torch.zeros(1536, 8, 2, device="cuda")
     with pytest.raises(RuntimeError, match="not taken by the direct"):
         nat.linear_ln(x, w, ln=(st, torch.zeros(1280, device="cuda"), torch.zeros(1280, device="cuda")))
+
+
+@pytest.mark.parametrize("Ci,Co,H,imgs,up", [(256, 256, 64, 16, False), (512, 512, 32, 16, False), (512, 256, 64, 8, False), (256, 256, 32, 16, True)])
+def test_conv_big_tile_ragged_width(nat, Ci, Co, H, imgs, up):
+    """3x3 convs whose width is not a multiple of the 320-column tile (the temporal VAE: 256, 512) on the 256x320 tile with a partly filled last
+    column tile (round 5), tap-inner and plain k order, with and without the fused nearest x2: vs torch fp32 on the same fp16 inputs"""
+    x = rnd(imgs, H, H, Ci, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=1 / math.sqrt(9 * Ci))
+    b, r = rnd(Co, seed=3), rnd(imgs, H * (2 if up else 1), H * (2 if up else 1), Co, seed=4)
+    xin = x.float().permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.float(), b.float(), padding=1).permute(0, 2, 3, 1) + r.float()
+    wn = w.permute(0, 2, 3, 1).reshape(Co, 9, Ci).contiguous()
+    close(nat.conv_nhwc(x, wn, bias=b, residual=r, upsample=up), ref)
+    if not up:
+        wti = w.reshape(Co, Ci // 64, 64, 9).permute(0, 1, 3, 2).contiguous()
+        close(nat.conv_nhwc_tapinner(x, wti, bias=b, residual=r), ref)

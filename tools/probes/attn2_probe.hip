@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
     }
     std::vector<long long> h(nb * 32);
     hipMemcpy(h.data(), tr, nb * 32 * 8, hipMemcpyDeviceToHost);
-    const char* names[7] = {"X DMA + first weight frags -> barrier", "phase A k loop", "barrier", "Q write (LN epilogue)", "phase B (2 heads)", "phase C k loop (incl. its barrier wait)",
+    const char* names[7] = {"X DMA + first weight frags -> barrier", "phase A k loop", "barrier + Q write (LN epilogue)", "-", "phase B (2 heads)", "phase C k loop (incl. its barrier wait)",
                             "residual wait + Y tile + row pass + stores"};
     const int a[7] = {0, 1, 2, 3, 3, 5, 6}, b[7] = {1, 2, 3, 3, 4, 6, 7};
     double sum[8] = {0}, tot = 0;
@@ -63,8 +63,9 @@ int main(int argc, char** argv) {
     // barrier wait before phase C: slot 4 -> 5
     double bw = 0;
     for (long w = 0; w < nb * 4; ++w) bw += (double)(h[w * 8 + 5] - h[w * 8 + 4]);
-    printf("per wave, mean cycles of the counter (100 MHz s_memtime ticks x?): total %.0f\n", tot / (nb * 4));
-    for (int i = 0; i < 7; ++i) printf("  %-50s %9.0f\n", names[i], sum[i] / (nb * 4));
+    printf("per wave, mean shader-clock cycles (s_memtime): total %.0f\n", tot / (nb * 4));
+    for (int i = 0; i < 7; ++i)
+        if (i != 3) printf("  %-50s %9.0f\n", names[i], sum[i] / (nb * 4));
     printf("  %-50s %9.0f\n", "  (of which: weight prefetch + barrier before phase C)", bw / (nb * 4));
     long long tmin = h[0], tmax = h[7];
     for (long w = 0; w < nb * 4; ++w) { if (h[w * 8] < tmin) tmin = h[w * 8]; if (h[w * 8 + 7] > tmax) tmax = h[w * 8 + 7]; }

@@ -1424,8 +1424,10 @@ static const BigEnv& big_env() {
 // ragged: a plain linear (no GEGLU, no LayerNorm fold / statistics, no split-K) may end in a partly filled column tile (N % 8 == 0):
 // the MM-DiT widths of the SD3 path (1536, 4608, 6144 = 4.8 / 14.4 / 19.2 tiles) lose 4 % of the MFMA work to padding and still run
 // 1.4x faster than on the 128 x 128 tile.  Weight rows >= N come from the zero page; both epilogues skip columns >= N.
-static bool big_shape_ok(int N, int K, long x_elems, bool ragged = false) {      // x_elems: extent of the activation operand in elements (32-bit DMA offsets)
-    return !big_env().nobig && (N % 320 == 0 || (ragged && N % 8 == 0 && N >= 640)) && (long)N * K < (1L << 31) && x_elems < (1L << 31);
+// (round 5: ragged_min — convolutions of widths 256 / 512 (the temporal VAE: a last column tile 80 % / 60 % full) also take the 256x320 tile: 900+ TFLOP/s of
+// useful work against ~500 on the 128 x 128 tile; UNIVST_CONV_RAGGED=0 switches that off)
+static bool big_shape_ok(int N, int K, long x_elems, bool ragged = false, int ragged_min = 640) {      // x_elems: extent of the activation operand in elements (32-bit DMA offsets)
+    return !big_env().nobig && (N % 320 == 0 || (ragged && N % 8 == 0 && N >= ragged_min)) && (long)N * K < (1L << 31) && x_elems < (1L << 31);
 }
 
 // Does a plain linear [M, K] (row stride ldx, 0 = K) x [N, K]^T take the direct (no split-K) 256x320 path whose epilogue can fold a
@@ -1552,7 +1554,11 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
         // rounds but 512 tiles of 192 = 2 exact ones; 12288 x 1280 is 192 vs 256 tiles)
         static const int bm_env = getenv("UNIVST_GEMM_BM") ? atoi(getenv("UNIVST_GEMM_BM")) : 0;     // A/B aid: force 256 / 192
         const long ncu = uv_num_cus();
-        const bool ragged = mode == 0 && !p.geglu && !lnf;
+        static const int conv_ragged = getenv("UNIVST_CONV_RAGGED") ? atoi(getenv("UNIVST_CONV_RAGGED")) : 1;
+        // a ragged last column tile: plain linears (N >= 640) and, since round 5, plain convs whose width fills a whole number of 64-column wave halves
+        // and at least 80 % of one tile (256, 512, 576, ...: not the UNet's widths, which are multiples of 320)
+        const bool conv_rag = mode == 1 && conv_ragged && !p.gn_out && p.N % 64 == 0 && p.N >= 256 && (p.N % 320 == 0 || p.N % 320 >= 192);
+        const bool ragged = (mode == 0 && !p.geglu && !lnf) || conv_rag;
         const int ntn_c = (p.N + 319) / 320;
         const long n256 = (long)((p.M + 255) / 256) * ntn_c, n192 = (long)((p.M + 191) / 192) * ntn_c;
         // per-row cost of the 192-row tile relative to the 256-row one, measured at equal round counts: convs 0.96-1.0, linears 1.02-1.07
@@ -1586,7 +1592,7 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
         const bool use_patch = patch_env && mode == 1 && (nblk >= bigmin || bsplits > 1) && uv_conv_patch_eligible(p, use192 ? 192 : 256);
         UV_REQUIRE(p.W || use_patch, "conv: only the [Cin/32][9][32] weight copy was given but the problem is not eligible for the LDS-patch kernel "
                    "(3x3, stride 1, whole image rows per 256/192-row tile, >= 150 tiles or a reduction long enough for split-K)");
-        if (big_shape_ok(p.N, p.K, xmax, ragged) && (nblk >= bigmin || bsplits > 1)) {
+        if (big_shape_ok(p.N, p.K, xmax, ragged, conv_rag ? 256 : 640) && (nblk >= bigmin || bsplits > 1)) {
             char sym[48];
             if (use_patch) snprintf(sym, sizeof sym, "conv_patch_kernel<%d>", use192 ? 3 : 4);
             else snprintf(sym, sizeof sym, "gemm_big_kernel<%d,%d,%d>", mode, use192 ? 3 : 4, mode == 0 ? (p.ln_stats ? 2 : (p.stats_out ? 1 : (mmdit_epi ? 3 : 0))) : 0);

@@ -47,6 +47,13 @@ __global__ void v_permute_conv_weight_kernel(const half_t* __restrict__ in, half
     const int c = (int)(i % CiP), t = (int)((i / CiP) % taps), o = (int)(i / ((long)CiP * taps));
     out[i] = c < Ci ? in[((long)o * Ci + c) * taps + t] : (half_t)0.f;
 }
+// [Co][Ci][3][3] -> tap-inner [Co][Ci/64][9][64] (GemmParams::korder = 1: the nine taps of a 64-channel slab are consecutive k tiles)
+__global__ void v_permute_conv_weight_ti_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int Co, int Ci) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)Co * Ci * 9) return;
+    const int j = (int)(i % 64), t = (int)((i / 64) % 9), q = (int)((i / (64 * 9)) % (Ci / 64)), o = (int)(i / ((long)Ci * 9));
+    out[i] = in[((long)o * Ci + q * 64 + j) * 9 + t];
+}
 __global__ void v_scale_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, long n, float f) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (half_t)((float)in[i] * f);
@@ -201,6 +208,12 @@ int Vae::finalize(hipStream_t s) {
             int rc = derive(k + "#nhwc", {Co, taps, CiP}, &d);
             if (rc) return rc;
             hipLaunchKernelGGL(v_permute_conv_weight_kernel, dim3(nb((long)Co * taps * CiP)), dim3(256), 0, s, t.ptr, d, Co, Ci, taps, CiP);
+            if (t.shape.size() == 4 && taps == 9 && Ci % 64 == 0) {      // tap-inner copy for the 256x320 tile's fast im2col addressing
+                half_t* d2;
+                rc = derive(k + "#ti", {Co, Ci / 64, 9, 64}, &d2);
+                if (rc) return rc;
+                hipLaunchKernelGGL(v_permute_conv_weight_ti_kernel, dim3(nb((long)Co * Ci * 9)), dim3(256), 0, s, t.ptr, d2, Co, Ci);
+            }
         } else if (ends(k, ".to_q.weight") || ends(k, ".to_q.bias")) {
             // the attention scale 1/sqrt(head_dim) (one head: head_dim = C) rides on the q projection, so the fp16 scores are the scaled ones
             long n = 1;
@@ -274,7 +287,8 @@ struct VFwd {
         g.M = a.imgs * g.Ho * g.Wo;
         g.N = Cout;
         g.K = taps * a.C;
-        g.W = W(p + ".weight#nhwc");
+        g.korder = (taps == 9 && !asym && stride == 1 && a.C % 64 == 0 && u.find(p + ".weight#ti")) ? 1 : 0;
+        g.W = W(p + (g.korder ? ".weight#ti" : ".weight#nhwc"));
         g.bias = W(p + ".bias");
         if (!g.W || !g.bias) return u.missing_error();
         g.R = R;
