@@ -234,6 +234,22 @@ int Vae::finalize(hipStream_t s) {
         UV_HIP(hipStreamSynchronize(s));
         mix[k.substr(0, k.size() - strlen(".time_mixer.mix_factor"))] = (float)h;
     }
+    // The AlphaBlender folded into the temporal block's second conv: blended = alpha * s + (1 - alpha) * (s + h) = s + sigmoid(mix) * h with h = conv2(...) + bias,
+    // so conv2's weight and bias are scaled by sigmoid(mix) once and the residual add of its epilogue IS the blend (one pass over three tensors less per block)
+    for (auto& kv : mix) {
+        const float sig = 1.f / (1.f + expf(-kv.second));
+        for (const char* suf : {".temporal_res_block.conv2.weight#nhwc", ".temporal_res_block.conv2.bias"}) {
+            const WTensor* t = find(kv.first + suf);
+            UV_REQUIRE(t, "%s%s missing", kv.first.c_str(), suf);
+            long n = 1;
+            for (long v : t->shape) n *= v;
+            half_t* d;
+            int rc = derive(kv.first + suf + "#mix", t->shape, &d);
+            if (rc) return rc;
+            hipLaunchKernelGGL(v_scale_kernel, dim3(nb(n)), dim3(256), 0, s, t->ptr, d, n, sig);
+        }
+    }
+    UV_LAUNCH_CHECK();
     UV_HIP(hipStreamSynchronize(s));
     finalized = true;
     return UV_OK;
@@ -304,7 +320,7 @@ struct VFwd {
         return uv_launch_gemm(g, 1, s);
     }
     // Conv3d (3,1,1) over the F frames of every pixel: the 3x1 tap geometry on (image rows = frames, image columns = pixels)
-    int frame_conv(const Act& a, int F, const std::string& p, const half_t* R, half_t* out) {
+    int frame_conv(const Act& a, int F, const std::string& p, const half_t* R, half_t* out, const char* mixsuf = "") {
         GemmParams g;
         g.X = a.p;
         g.C1 = a.C;
@@ -319,8 +335,8 @@ struct VFwd {
         g.M = (int)a.rows();
         g.N = a.C;
         g.K = 3 * a.C;
-        g.W = W(p + ".weight#nhwc");
-        g.bias = W(p + ".bias");
+        g.W = W(p + ".weight#nhwc" + mixsuf);
+        g.bias = W(p + ".bias" + mixsuf);
         if (!g.W || !g.bias) return u.missing_error();
         g.R = R;
         g.ldr = a.C;
@@ -371,7 +387,7 @@ struct VFwd {
         return UV_OK;
     }
     // diffusers TemporalResnetBlock (in == out channels, no time embedding) on [B, F, H, W, C]: GroupNorm over (C/G, F, H, W), eps 1e-5
-    // (Mid / UpBlockTemporalDecoder build their ST-resblocks with eps = 1e-6, temporal_eps = 1e-5)
+    // (Mid / UpBlockTemporalDecoder build their ST-resblocks with eps = 1e-6, temporal_eps = 1e-5), with the ST-resblock's AlphaBlender in its last epilogue
     int resnet_temporal(const std::string& p, const Act& x, int F, half_t* out) {
         const long rps = (long)F * x.H * x.W;
         half_t* n1 = alloc(x.rows() * x.C);
@@ -383,7 +399,7 @@ struct VFwd {
         RUN(frame_conv(n1a, F, p + ".conv1", nullptr, h));
         Act ha{h, x.imgs, x.H, x.W, x.C};
         RUN(groupnorm(ha, rps, p + ".norm2", 1, n1, 1e-5f));
-        RUN(frame_conv(n1a, F, p + ".conv2", x.p, out));
+        RUN(frame_conv(n1a, F, p + ".conv2", x.p, out, "#mix"));     // x + sigmoid(mix) * (conv2 + bias): the block's output AND the AlphaBlender (finalize)
         free(h);
         free(n1);
         return UV_OK;
@@ -396,10 +412,9 @@ struct VFwd {
         UV_REQUIRE(it != u.mix.end(), "%s: time_mixer.mix_factor missing", p.c_str());
         half_t* tp = alloc(sp.rows() * Cout);
         if (!tp) return UV_ERR_STATE;
-        RUN(resnet_temporal(p + ".temporal_res_block", sp, F, tp));
-        const float sig = 1.f / (1.f + expf(-it->second));
-        RUN(uv_launch_axpby(sp.p, tp, sp.p, 1.f - sig, sig, sp.rows() * Cout, s));      // alpha = 1 - sigmoid(mix) weighs the spatial branch
-        free(tp);
+        RUN(resnet_temporal(p + ".temporal_res_block", sp, F, tp));      // = alpha * spatial + (1 - alpha) * temporal, alpha = 1 - sigmoid(mix): folded into conv2
+        free(sp.p);
+        sp.p = tp;
         *out = sp;
         return UV_OK;
     }
