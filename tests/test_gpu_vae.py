@@ -206,3 +206,26 @@ def test_pixel_smoother_leg_runs_on_the_native_vae():
     print("pixel smoother on the native VAE: PSNR native-vs-oracle", vals, "unsmoothed-vs-oracle", off)
     assert all(v >= 35.0 for v in vals.values()), vals
     assert all(vals[i] >= off[i] + 6.0 for i in (20, 22, 24)), (vals, off)
+
+
+def test_vae_from_pretrained_reads_a_diffusers_directory_without_diffusers(nat, tmp_path):
+    """NativeTemporalVAE.from_pretrained: <dir>/vae/config.json + diffusion_pytorch_model.safetensors, the layout AutoencoderKLTemporalDecoder.from_pretrained reads
+    (src/sd/run_video_style_transfer_sd.py:36) — no diffusers import; same outputs as the handle built from the state dict"""
+    import json, sys
+    from safetensors.torch import save_file
+    from univst_amd import synth, vae
+    sd = synth.vae_state_dict(SMALL, seed=17)
+    d = tmp_path / "svd" / "vae"
+    d.mkdir(parents=True)
+    json.dump({"_class_name": "AutoencoderKLTemporalDecoder", "_diffusers_version": "0.24.0", "block_out_channels": list(SMALL["block_out_channels"]),
+               "down_block_types": ["DownEncoderBlock2D"] * 4, "force_upcast": True, "in_channels": 3, "latent_channels": 4, "layers_per_block": 2,
+               "out_channels": 3, "sample_size": 768, "scaling_factor": 0.18215}, open(d / "config.json", "w"))
+    save_file({k: v.cpu().contiguous() for k, v in sd.items()}, str(d / "diffusion_pytorch_model.safetensors"))
+    had = "diffusers" in sys.modules
+    v = vae.NativeTemporalVAE.from_pretrained(str(tmp_path / "svd"), subfolder="vae")
+    assert ("diffusers" in sys.modules) == had, "from_pretrained must not import diffusers"
+    assert v.config.scaling_factor == 0.18215 and tuple(v.config.block_out_channels) == tuple(SMALL["block_out_channels"])
+    z = torch.randn(4, 4, 8, 8, generator=torch.Generator().manual_seed(3)).half().cuda()
+    assert torch.equal(v.decode(z, num_frames=4).sample, vae.NativeTemporalVAE(sd, SMALL).decode(z, num_frames=4).sample)
+    with pytest.raises(FileNotFoundError):
+        vae.NativeTemporalVAE.from_pretrained(str(tmp_path / "nowhere"))

@@ -10,22 +10,33 @@ import torch
 
 
 def build_pipeline(pretrained_model_path, weight_dtype=torch.float16, vae_path="stabilityai/stable-video-diffusion-img2vid"):
+    """The objects run_*_sd.py build (src/sd/run_video_style_transfer_sd.py:30-47).  diffusers is needed only where a local directory cannot be read
+    without it: the VAE loads natively from ``<vae_path>/vae`` (config.json + safetensors / bin) when that is a directory, and the DDIM scheduler
+    is the native one (same ``from_pretrained(path, subfolder="scheduler")``) when diffusers is absent."""
     from transformers import CLIPTextModel, CLIPTokenizer
-    try:
-        from diffusers import AutoencoderKLTemporalDecoder, DDIMScheduler
-    except ImportError as e:  # pragma: no cover
-        raise RuntimeError("the CLI needs `diffusers` for the temporal VAE (third-party model, not re-implemented); "
-                           "the native UNet / pipeline classes themselves do not") from e
     from ...backbones.video_diffusion_sd.models.unet_3d_condition import UNetPseudo3DConditionModel
     from ...backbones.video_diffusion_sd.pipelines.stable_diffusion import SpatioTemporalStableDiffusionPipeline
+    from ...vae import NativeTemporalVAE
+    try:
+        from diffusers import DDIMScheduler
+    except ImportError:
+        from ...schedulers import DDIMScheduler
     tokenizer = CLIPTokenizer.from_pretrained(pretrained_model_path, subfolder="tokenizer")
     text_encoder = CLIPTextModel.from_pretrained(pretrained_model_path, subfolder="text_encoder").requires_grad_(False)
-    vae = AutoencoderKLTemporalDecoder.from_pretrained(vae_path, subfolder="vae").requires_grad_(False)
+    vae = None
+    stock = os.environ.get("UNIVST_VAE", "native") == "stock"
+    if not stock and os.path.isdir(os.path.join(vae_path, "vae")):
+        vae = NativeTemporalVAE.from_pretrained(vae_path, subfolder="vae")
+    if vae is None:
+        try:
+            from diffusers import AutoencoderKLTemporalDecoder
+        except ImportError as e:  # pragma: no cover
+            raise RuntimeError(f"the temporal VAE could not be loaded: {vae_path}/vae is not a local diffusers-format directory and `diffusers` (which would resolve "
+                               "it from the hub cache) is not installed") from e
+        vae = AutoencoderKLTemporalDecoder.from_pretrained(vae_path, subfolder="vae").requires_grad_(False).to(weight_dtype).cuda()
+        if not stock:
+            vae = NativeTemporalVAE.from_module(vae)
     unet = UNetPseudo3DConditionModel.from_2d_model(os.path.join(pretrained_model_path, "unet")).requires_grad_(False)
-    vae = vae.to(weight_dtype).cuda()
-    if os.environ.get("UNIVST_VAE", "native") != "stock":
-        from ...vae import NativeTemporalVAE
-        vae = NativeTemporalVAE.from_module(vae)
     pipe = SpatioTemporalStableDiffusionPipeline(
         vae=vae, text_encoder=text_encoder.to(weight_dtype).cuda(), tokenizer=tokenizer,
         unet=unet.to(weight_dtype).cuda(), scheduler=DDIMScheduler.from_pretrained(pretrained_model_path, subfolder="scheduler"))

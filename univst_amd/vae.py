@@ -66,6 +66,33 @@ class NativeTemporalVAE(torch.nn.Module):
 
     from_state_dict = classmethod(lambda cls, sd, config=None, device="cuda": cls(sd, config=config, device=device))
 
+    @classmethod
+    def from_pretrained(cls, path, subfolder="vae", device="cuda", **_):
+        """Load a diffusers-format VAE directory WITHOUT diffusers: ``<path>/<subfolder>/config.json`` + ``diffusion_pytorch_model[.fp16].safetensors``
+        (or ``.bin``) — what ``AutoencoderKLTemporalDecoder.from_pretrained(path, subfolder="vae")`` reads (src/sd/run_*_sd.py:36-42).  Local directories
+        only (the target boxes have no hub access); raises FileNotFoundError otherwise so that a caller can fall back to diffusers."""
+        import json
+        import os
+        d = os.path.join(path, subfolder) if subfolder else path
+        cfg_file = os.path.join(d, "config.json")
+        if not os.path.isfile(cfg_file):
+            raise FileNotFoundError(f"{cfg_file} not found (NativeTemporalVAE.from_pretrained needs a local diffusers-format directory)")
+        with open(cfg_file) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        cls_name = json.load(open(cfg_file)).get("_class_name", "AutoencoderKLTemporalDecoder")
+        if cls_name != "AutoencoderKLTemporalDecoder":
+            raise ValueError(f"{cfg_file}: _class_name = {cls_name}; the native VAE restates AutoencoderKLTemporalDecoder only")
+        for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.bin"):
+            w = os.path.join(d, name)
+            if os.path.isfile(w):
+                if name.endswith(".safetensors"):
+                    from safetensors.torch import load_file
+                    sd = load_file(w)
+                else:
+                    sd = torch.load(w, map_location="cpu")
+                return cls(sd, config=cfg, device=device)
+        raise FileNotFoundError(f"no diffusion_pytorch_model.safetensors / .bin under {d}")
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
