@@ -418,7 +418,10 @@ struct VFwd {
         *out = sp;
         return UV_OK;
     }
-    // diffusers Attention(heads = 1, dim_head = C, norm_num_groups, residual_connection, bias) over the H*W tokens of every image
+    // diffusers Attention(heads = 1, dim_head = C, norm_num_groups, residual_connection, bias) over the H*W tokens of every image.
+    // Numerics: the scaled scores of a frame are stored in fp16 between the QK^T GEMM and the row softmax (|ds| <= 2^-11 |s|: for logits of a few tens
+    // that is the size of the error the fp16 q and k rows themselves carry — the reference runs this VAE in fp16 too, `vae.to(weight_dtype)`); the softmax
+    // arithmetic and the PV accumulation are fp32.  A d = 512 flash kernel would avoid the N x N round trip; at 64 x 64 tokens the two GEMMs take 2 % of a decode.
     int attention(const std::string& p, const Act& x, Act* out) {
         const int C = x.C, N = x.H * x.W;
         const long rows = x.rows();
