@@ -128,7 +128,8 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
  *   "gn_fold" (default 1, env UNIVST_GN_FOLD): the per-frame GroupNorm in front of a transformer block (attention.py:121) is folded into proj_in as per-frame
  *             weight sets + an fp32 bias where the copies are cheap against the apply pass they replace (the 64x64 level); 0: always the apply pass.
  *   "attn2_fused" (default 1, env UNIVST_ATTN2_FUSED=0 disables it library-wide): the text cross-attention of a transformer block (attention.py:321-327)
- *             as one launch (univst_attn2_fused) where the level's shape is served, instead of q projection + attention + out projection. */
+ *             as one launch (univst_attn2_fused) where the level's shape is served, instead of q projection + attention + out projection; 2 (default): with the
+ *             self-attention's out projection + residual in front of it (univst_attn12_fused), 1: attn2 alone, 0: off. */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
 
 /* ------------------------------------------------------------------ temporal VAE handle
@@ -199,6 +200,14 @@ int univst_attn2_fused(const void* X, int64_t ldx, const float* ln_stats, float 
                        const void* Wq_frag, int q_prescaled, const void* kv, int B, int T, int64_t rows_per_branch, const void* Wo_frag,
                        const void* bias_o, const void* residual, int64_t ldr, void* Y, int64_t ldy, int64_t M, int C, int heads,
                        float* stats_out, void* workspace, void* stream);
+/* The same with the SELF-attention's out projection in front (attention.py:316-327: attn1.to_out + hidden_states -> norm2 -> attn2 -> + hidden_states):
+ *     H2 = attn_out Wp^T + bias_p + residual_in;   Y = to_out( attention( LN(H2) Wq^T, text K, text V ) ) + bias_o + H2
+ * H2 — which only this block reads — stays in LDS; its LayerNorm statistics are taken inside (ln_wsum / ln_bias as in univst_linear_ln, Wq_frag from the
+ * gamma-folded weight).  Replaces univst_linear_ln (attn1.to_out, stats_out) + univst_attn2_fused.  Same shapes as univst_attn2_fused. */
+int univst_attn12_fused(const void* attn_out, int64_t ldx, const void* Wp_frag, const void* bias_p, const void* residual_in, int64_t ldr_in, float ln_eps,
+                        const float* ln_wsum, const float* ln_bias, const void* Wq_frag, int q_prescaled, const void* kv, int B, int T,
+                        int64_t rows_per_branch, const void* Wo_frag, const void* bias_o, void* Y, int64_t ldy, int64_t M, int C, int heads,
+                        float* stats_out, void* workspace, void* stream);
 /* W [N][K] (N % 16 == 0, K % 32 == 0) -> the order in which v_mfma_f32_16x16x32_f16 takes it as its A operand: [N/16][K/32][64 lanes][8 halfs],
  * lane (l15, g) = W[nf*16 + l15][ks*32 + g*8 .. +8] — one contiguous 1 KB load per fragment for kernels that read weights straight into registers. */
 int univst_frag_pack(const void* W, void* out, int N, int K, void* stream);

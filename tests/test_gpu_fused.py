@@ -165,3 +165,42 @@ def test_linear_sets_refuses_what_the_direct_path_does_not_take(nat):
     x = torch.zeros(1536, 320).half().cuda()
     with pytest.raises(RuntimeError, match="direct 256x320 path"):
         nat.linear_sets(x, torch.zeros(2, 320, 320).half().cuda(), torch.zeros(2, 320, device="cuda"), 768)
+
+
+@pytest.mark.parametrize("M,rpb,row_mean", [(3 * 4096, 4096, 0.7), (2 * 1024 + 37, 1024, 0.7), (2 * 640, 640, 30.0)])
+def test_attn12_fused_matches_the_two_step_path_and_torch(nat, M, rpb, row_mean):
+    """univst_attn12_fused (attn1.to_out + residual in front of the fused text cross-attention; H2 stays in LDS, LayerNorm statistics taken inside) against
+    torch fp32 and against univst_linear + univst_attn2_fused (which differ only in where the statistics come from)"""
+    C, heads, T = 320, 8, 77
+    d = C // heads
+    g = torch.Generator().manual_seed(M)
+    B = -(-M // rpb)
+    ao = torch.randn(M, C, generator=g).half().cuda()
+    hin = (torch.randn(M, C, generator=g) + row_mean).half().cuda()
+    wp = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    bp = (0.3 * torch.randn(C, generator=g)).half().cuda()
+    gamma = (1.0 + 0.3 * torch.randn(C, generator=g)).half().cuda()
+    beta = (0.2 * torch.randn(C, generator=g)).half().cuda()
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    wo = (torch.randn(C, C, generator=g) / math.sqrt(C)).half().cuda()
+    bo = (0.1 * torch.randn(C, generator=g)).half().cuda()
+    kv = torch.randn(B * T, 2 * C, generator=g).half().cuda()
+    wqs = (wq.float() * (math.log2(math.e) / math.sqrt(d))).half()
+    wl = (wqs.float() * gamma.float()[None]).half()
+    wsum, lnb = wl.float().sum(1).contiguous(), (wqs.float() @ beta.float()).contiguous()
+    st = torch.full((M, 2, 2), float("nan"), device="cuda")
+    got = nat.attn12_fused(ao, nat.frag_pack(wp), bp, hin, nat.frag_pack(wl), wsum, lnb, kv, nat.frag_pack(wo), bo, rpb, heads, q_prescaled=True, stats_out=st).float()
+    h2 = (ao.float() @ wp.float().t() + bp.float() + hin.float()).half()
+    xn = F.layer_norm(h2.float(), (C,), gamma.float(), beta.float(), 1e-5)
+    want = _attn2_ref(xn, wq, kv, wo, bo, h2, rpb, heads)
+    scale = want.abs().max().item()
+    mx = (got - want).abs().max().item() / scale
+    rms = ((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    assert mx < 3e-3 and rms < 1e-3, (mx, rms)
+    h2n = nat.linear(ao, wp, bias=bp, residual=hin)
+    h2f = h2n.float()
+    stats = torch.stack([h2f.view(M, 2, 160).sum(-1), (h2f * h2f).view(M, 2, 160).sum(-1)], -1).contiguous()
+    two = nat.attn2_fused(h2n, nat.frag_pack(wl), kv, nat.frag_pack(wo), bo, rpb, heads, ln=(stats, wsum, lnb), q_prescaled=True).float()
+    assert (got - two).abs().max().item() / scale < 1.5e-3
+    want_st = torch.stack([got.view(M, 2, 160).sum(-1), (got * got).view(M, 2, 160).sum(-1)], -1)
+    assert torch.allclose(st, want_st, rtol=2e-5, atol=2e-3)

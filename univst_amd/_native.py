@@ -79,6 +79,7 @@ SIGNATURES = {
     "univst_vae_decode": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "univst_vae_encode": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "univst_attn2_fused_workspace_bytes": (_L, [_I, _I, _I]),
+    "univst_attn12_fused": (_I, [_P, _L, _P, _P, _P, _L, _F, _P, _P, _P, _I, _P, _I, _I, _L, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "univst_attn2_fused": (_I, [_P, _L, _P, _F, _P, _P, _P, _I, _P, _I, _I, _L, _P, _P, _P, _L, _P, _L, _L, _I, _I, _P, _P, _P]),
     "univst_conv_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
     "univst_conv_nhwc_tapinner": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P]),
@@ -234,6 +235,21 @@ def attn2_fused(x, wq_frag, kv, wo_frag, bias_o, rows_per_branch, heads, residua
     check(load().univst_attn2_fused(ptr(x), x.stride(0), ptr(st), eps, ptr(ws), ptr(lb), ptr(wq_frag), int(q_prescaled), ptr(kv), B, T,
                                     rows_per_branch, ptr(wo_frag), ptr(bias_o), ptr(residual), residual.stride(0), ptr(out), out.stride(0), M, C_,
                                     heads, ptr(stats_out), ptr(wsb), stream_ptr()), "attn2_fused")
+    return out
+
+
+def attn12_fused(attn_out, wp_frag, bias_p, residual_in, wq_frag, wsum, lnb, kv, wo_frag, bias_o, rows_per_branch, heads, q_prescaled=False, stats_out=None,
+                 eps=1e-5):
+    """attn1.to_out + residual -> LayerNorm -> text cross-attention -> to_out + residual in one launch (univst_attn12_fused)."""
+    _f16(attn_out), _f16(wp_frag), _f16(residual_in), _f16(wq_frag), _f16(kv), _f16(wo_frag)
+    M, C_ = attn_out.shape
+    B = -(-M // rows_per_branch)
+    T = kv.shape[0] // B
+    out = torch.empty(M, C_, device=attn_out.device, dtype=torch.float16)
+    wsb = torch.empty(max(int(load().univst_attn2_fused_workspace_bytes(B, heads, C_ // heads)), 16), device=attn_out.device, dtype=torch.uint8)
+    check(load().univst_attn12_fused(ptr(attn_out), attn_out.stride(0), ptr(wp_frag), ptr(bias_p), ptr(residual_in), residual_in.stride(0), eps, ptr(wsum), ptr(lnb),
+                                     ptr(wq_frag), int(q_prescaled), ptr(kv), B, T, rows_per_branch, ptr(wo_frag), ptr(bias_o), ptr(out), out.stride(0), M, C_, heads,
+                                     ptr(stats_out), ptr(wsb), stream_ptr()), "attn12_fused")
     return out
 
 

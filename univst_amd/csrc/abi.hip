@@ -58,6 +58,7 @@ int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     if (const char* e = getenv("UNIVST_LN_FOLD")) h->impl.ln_fold = atoi(e) < 0 ? 0 : (atoi(e) > 2 ? 2 : atoi(e));
     if (const char* e = getenv("UNIVST_GN_PRODUCER")) h->impl.gn_producer = atoi(e) != 0;
     if (const char* e = getenv("UNIVST_GN_FOLD")) h->impl.gn_fold = atoi(e) != 0;
+    if (const char* e = getenv("UNIVST_ATTN2_PRE")) h->impl.attn2_fused = atoi(e) ? 2 : 1;
     if (const char* e = getenv("UNIVST_CHAIN_BANDS")) h->impl.chain_bands = atoi(e) < 0 ? 0 : atoi(e);
     *out = h;
     return UV_OK;
@@ -74,7 +75,8 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value) {
         return UV_OK;
     }
     if (!strcmp(name, "attn2_fused")) {
-        h->impl.attn2_fused = value != 0;
+        UV_REQUIRE(value >= 0 && value <= 2, "unet_set_option: attn2_fused is 0, 1 or 2");
+        h->impl.attn2_fused = value;
         return UV_OK;
     }
     if (!strcmp(name, "gn_producer")) {
@@ -216,6 +218,28 @@ int univst_attn2_fused(const void* X, int64_t ldx, const float* ln_stats, float 
     p.q_prescaled = q_prescaled; p.scale_log2e = 1.4426950408889634f / sqrtf((float)(C / heads));
     p.Wo_f = H(Wo_frag); p.bias_o = H(bias_o);
     p.R = H(residual); p.ldr = ldr;
+    p.Y = HM(Y); p.ldy = ldy;
+    p.stats_out = stats_out;
+    return uv_launch_attn2_fused(p, C, S(s));
+}
+int univst_attn12_fused(const void* attn_out, int64_t ldx, const void* Wp_frag, const void* bias_p, const void* residual_in, int64_t ldr_in, float ln_eps,
+                        const float* ln_wsum, const float* ln_bias, const void* Wq_frag, int q_prescaled, const void* kv, int B, int T, int64_t rows_per_branch,
+                        const void* Wo_frag, const void* bias_o, void* Y, int64_t ldy, int64_t M, int C, int heads, float* stats_out, void* workspace, void* s) {
+    UV_REQUIRE(attn_out && Wp_frag && residual_in && ln_wsum && ln_bias && Wq_frag && kv && Wo_frag && Y && workspace, "attn12_fused: null argument");
+    UV_REQUIRE(B >= 1 && M >= 1 && M <= (int64_t)B * rows_per_branch && M < (1LL << 31) && heads > 0 && C % heads == 0, "attn12_fused: M=%lld rows exceed B=%d branches of %lld rows",
+               (long long)M, B, (long long)rows_per_branch);
+    UV_REQUIRE(uv_attn2_fused_ok(C, heads, (int)rows_per_branch, T), "attn12_fused: C=%d heads=%d rows_per_branch=%lld keys=%d is not a shape this kernel serves "
+               "(C = 320, 8 heads, rows per branch a multiple of 64, <= 80 keys)", C, heads, (long long)rows_per_branch, T);
+    int rc = uv_launch_kv_frag_pack(H(kv), HM(workspace), B, T, C, heads, S(s));
+    if (rc) return rc;
+    Attn2Params p;
+    p.X = H(attn_out); p.ldx = ldx; p.M = (int)M;
+    p.Wp_f = H(Wp_frag); p.bias_p = H(bias_p); p.Rp = H(residual_in); p.ldrp = ldr_in;
+    p.ln_slots = C / 160; p.ln_eps = ln_eps; p.ln_wsum = ln_wsum; p.ln_bias = ln_bias;
+    p.Wq_f = H(Wq_frag); p.kvf = H(workspace);
+    p.rows_per_branch = (int)rows_per_branch; p.heads = heads; p.Nkv = T;
+    p.q_prescaled = q_prescaled; p.scale_log2e = 1.4426950408889634f / sqrtf((float)(C / heads));
+    p.Wo_f = H(Wo_frag); p.bias_o = H(bias_o);
     p.Y = HM(Y); p.ldy = ldy;
     p.stats_out = stats_out;
     return uv_launch_attn2_fused(p, C, S(s));

@@ -88,8 +88,15 @@ __global__ __launch_bounds__(256) void kv_frag_pack_kernel(const half_t* __restr
 
 // OCC: resident blocks per CU the register budget is set for (2: 256 VGPRs, weight ring three k steps deep; 3: 168 VGPRs, ring two deep).  The tile is
 // the only LDS object (40 KB at C = 320: the row-statistics scratch reuses it once every thread holds its output chunks), so LDS allows either.
-template <int C, int D, bool LNF, int OCC = 2>
+// PRE (round 5, second step): the SELF-attention's out projection in front — X holds the attention output rows, phase P computes
+//     H2 = X Wp^T + bias_p + Rp          (attention.py:316-319: attn1.to_out + hidden_states)
+// into the tile AND into a second tile that stays as the residual of the last phase; the LayerNorm statistics of H2 are taken from the tile by the
+// waves themselves (no producer statistics, no block-wide scratch: lane (l15, g) sums row 16 g + l15 and the four rows a lane needs come back by
+// shuffle), so H2 — which nothing else reads — never reaches HBM and the out-projection launch disappears.  LDS: two 40 KB tiles = 80 KB, two blocks per CU
+// still fit (tools/probes: 0.182 ms with either footprint).
+template <int C, int D, bool LNF, int OCC = 2, bool PRE = false>
 __global__ __launch_bounds__(256, OCC) void attn2_fused_kernel(Attn2Params p) {
+    static_assert(!PRE || LNF, "the fused out projection computes the LayerNorm statistics itself");
     constexpr int BM = 64, NKT = C / 64, KSTEPS = C / 32, NFW = C / 64;       // NFW: 16-column fragments per wave (C/4 columns)
     constexpr int KS = (D + 31) / 32, DV16 = (D + 15) / 16, NKF = 5;
     constexpr int KVF = (NKF * KS + DV16 * 3) * 64 * 8;                       // halfs per (branch, head) in kvf
@@ -97,7 +104,12 @@ __global__ __launch_bounds__(256, OCC) void attn2_fused_kernel(Attn2Params p) {
     constexpr int TILE = BM * C;
     static_assert((C / 4) % D == 0 && (C / 4) / D == 2, "a wave owns two whole heads");
     constexpr int RING = OCC >= 3 ? 2 : 3;                                    // weight fragments in flight: RING k steps
-    __shared__ __attribute__((aligned(16))) half_t smem[TILE];
+#ifdef UV_A2_LDS2            // probe only: does a second 40 KB tile still leave two blocks per CU (2 x 80 KB = all of the LDS)?  (it does)
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * TILE];
+#else
+    __shared__ __attribute__((aligned(16))) half_t smem[PRE ? 2 * TILE : TILE];
+#endif
+    half_t* const Rt = smem + TILE;                                           // PRE: H2, kept for the residual add of the last phase
     half_t* const T = smem;
     float2* const scr = reinterpret_cast<float2*>(smem);                      // row-statistics scratch: the tile, after the last read of it (BM * CH float2 = half the tile)
 
@@ -155,7 +167,51 @@ __global__ __launch_bounds__(256, OCC) void attn2_fused_kernel(Attn2Params p) {
 
     // ---- phase A: Q = LN(X) Wq'^T
     float2 lnrow[LNF ? 4 : 1];
-    if constexpr (LNF) {
+    if constexpr (PRE) {
+        // ---- phase P: H2 = X Wp^T + bias_p + Rp.  The residual rows are requested before the k loop (MFMA layout: 8 bytes per fragment and lane)
+        const int nb = wave * (C / 4) + g * 4;
+        h4 hres[NFW][4];
+#pragma unroll
+        for (int i = 0; i < NFW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + j * 16 + l15;
+                hres[i][j] = m < p.M ? *reinterpret_cast<const h4*>(p.Rp + (long)m * p.ldrp + nb + i * 16) : h4{0, 0, 0, 0};
+            }
+        project(p.Wp_f, true, 1);
+        __syncthreads();                             // every wave is done reading the attention output: the tile becomes H2
+#pragma unroll
+        for (int i = 0; i < NFW; ++i) {
+            h4 bv = {0, 0, 0, 0};
+            if (p.bias_p) bv = *reinterpret_cast<const h4*>(p.bias_p + nb + i * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h4 hv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[r] = (half_t)(acc[i][j][r] + (float)bv[r] + (float)hres[i][j][r]);      // one rounding, as the unfused epilogue
+                const int off = tile_off(j * 16 + l15, nb + i * 16);
+                *reinterpret_cast<h4*>(&T[off]) = hv;
+                *reinterpret_cast<h4*>(&Rt[off]) = hv;
+            }
+        }
+        __syncthreads();                             // H2 complete
+        // LayerNorm statistics of the stored fp16 rows: lane (l15, g) takes row 16 g + l15 (every wave all 64 rows: no cross-wave exchange)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < CH; ++c8) {
+            const h8 v = *reinterpret_cast<const h8*>(&T[tile_off(g * 16 + l15, c8 * 8)]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = (float)v[e];
+                s1 += t;
+                s2 = fmaf(t, t, s2);
+            }
+        }
+        const float mean = s1 * (1.f / C);
+        const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, s2 * (1.f / C)), 0.f) + p.ln_eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lnrow[j] = float2{__shfl(mean, j * 16 + l15, 64), __shfl(rstd, j * 16 + l15, 64)};
+    } else if constexpr (LNF) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + j * 16 + l15;
@@ -300,7 +356,8 @@ __global__ __launch_bounds__(256, OCC) void attn2_fused_kernel(Attn2Params p) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int id = it * 256 + tid, row = id / CH, c8 = id - row * CH;
-        res[it] = (m0 + row < p.M) ? *reinterpret_cast<const h8*>(p.R + (long)(m0 + row) * p.ldr + c8 * 8) : zero8;
+        if constexpr (PRE) res[it] = *reinterpret_cast<const h8*>(&Rt[tile_off(row, c8 * 8)]);      // H2 never left the block
+        else res[it] = (m0 + row < p.M) ? *reinterpret_cast<const h8*>(p.R + (long)(m0 + row) * p.ldr + c8 * 8) : zero8;
     }
     __syncthreads();                                 // every wave is done reading O: the tile becomes Y
     {
@@ -395,15 +452,19 @@ int uv_launch_attn2_fused(const Attn2Params& p, int C, hipStream_t s) {
     auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     UV_REQUIRE(p.M > 0 && uv_attn2_fused_ok(C, p.heads, p.rows_per_branch, p.Nkv), "attn2_fused: C=%d heads=%d rows_per_branch=%d Nkv=%d is not a shape this kernel serves "
                "(C = 320, 8 heads, rows per branch a multiple of 64, <= 80 keys)", C, p.heads, p.rows_per_branch, p.Nkv);
-    UV_REQUIRE(p.X && p.R && p.Y && p.Wq_f && p.Wo_f && p.kvf && p.ldx % 8 == 0 && p.ldr % 8 == 0 && p.ldy % 8 == 0 && al16(p.X) && al16(p.R) && al16(p.Y) && al16(p.bias_o) &&
+    const bool pre = p.Wp_f != nullptr;
+    UV_REQUIRE(p.X && (p.R || pre) && p.Y && p.Wq_f && p.Wo_f && p.kvf && p.ldx % 8 == 0 && p.ldr % 8 == 0 && p.ldy % 8 == 0 && al16(p.X) && al16(p.R) && al16(p.Y) && al16(p.bias_o) &&
                (!p.ln_stats || (p.ln_wsum && p.ln_bias && p.ln_slots > 0)), "attn2_fused: null / misaligned operand");
-    const double fl = 4.0 * p.M * (double)C * C + 4.0 * p.M * (double)p.Nkv * C;
+    UV_REQUIRE(!pre || (p.Rp && p.ldrp % 4 == 0 && (reinterpret_cast<uintptr_t>(p.Rp) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.bias_p) & 7) == 0 && p.ln_wsum && p.ln_bias && !p.ln_stats),
+               "attn2_fused: the fused out projection needs its residual rows (8-byte aligned), the folded q weight's wsum / lnb, and no producer statistics");
+    const double fl = (pre ? 6.0 : 4.0) * p.M * (double)C * C + 4.0 * p.M * (double)p.Nkv * C;
     uv_prof_begin(UV_CLS_ATTN2_FUSED, fl, 2.0 * (3.0 * p.M * C + 2.0 * C * C), s);
     const dim3 grid((p.M + 63) / 64);
     // (measured and not instantiated: OCC = 3 — three resident blocks per CU at 168 VGPRs, weight ring two deep — 0.190 against 0.182 ms: every phase
     // of a block gets slower (phase A 7.7 k -> 14.6 k cycles per wave), i.e. the kernel is bound by what the blocks of a CU share — weight delivery
     // out of L2, the LDS port, the VALU port of phase B — not by latency a third block could hide)
-    if (p.ln_stats) hipLaunchKernelGGL((attn2_fused_kernel<320, 40, true>), grid, dim3(256), 0, s, p);
+    if (pre) hipLaunchKernelGGL((attn2_fused_kernel<320, 40, true, 2, true>), grid, dim3(256), 0, s, p);
+    else if (p.ln_stats) hipLaunchKernelGGL((attn2_fused_kernel<320, 40, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attn2_fused_kernel<320, 40, false>), grid, dim3(256), 0, s, p);
     uv_prof_end(s);
     UV_LAUNCH_CHECK();

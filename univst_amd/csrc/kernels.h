@@ -116,6 +116,12 @@ struct Attn2Params {
     half_t* Y = nullptr;
     long ldy = 0;
     float* stats_out = nullptr;         // [M][C/160][2] row statistics of Y for a following folded LayerNorm, or null
+    // the self-attention's out projection fused in front (attention.py:316-319): X = attention output rows, H2 = X Wp^T + bias_p + Rp is the block's input
+    // AND residual and never reaches memory; the LayerNorm statistics are taken inside (ln_stats null, ln_wsum / ln_bias set)
+    const half_t* Wp_f = nullptr;       // attn1.to_out weight in operand order, or null: no fused out projection
+    const half_t* bias_p = nullptr;
+    const half_t* Rp = nullptr;         // its residual rows [M, ldrp]
+    long ldrp = 0;
 #ifdef UV_A2_TRACE
     long long* trace = nullptr;         // tools/probes/attn2_probe.hip: [blocks][4 waves][8] cycle counter at the phase boundaries
 #endif

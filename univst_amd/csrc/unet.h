@@ -58,7 +58,7 @@ struct UNet {
     int gn_producer = 1;      // GroupNorm statistics from the producing conv / linear's epilogue where the tile geometry allows (UNIVST_GN_PRODUCER=0: always the stand-alone pass)
     int chain_bands = 1;      // post-attention chain of a transformer block in row bands: 1 off (default: measured +0.4 ms per step in the graph), 0 auto (bands of >= 65536 rows), n > 1 forced (UNIVST_CHAIN_BANDS)
     int gn_fold = 1;          // the transformer blocks' per-frame GroupNorm folded into proj_in where the weight copies are cheap (round 5; 0: the apply pass)
-    int attn2_fused = 1;      // the text cross-attention of a block as one launch where fused.hip serves the shape (round 5; 0: q projection + attention + out projection)
+    int attn2_fused = 2;      // the text cross-attention of a block as one launch where fused.hip serves the shape (round 5): 2 = with the self-attention's out projection in front, 1 = attn2 alone, 0 = q projection + attention + out projection
     int ln_fold = 2;          // transformer-block LayerNorms folded into the neighbouring linears: 0 none, 1 norm1 + norm2, 2 also norm3 (default since round 4; UNIVST_LN_FOLD)
     unsigned* d_counter = nullptr;
     // TRAINED temporal layers (fine-tuned 3-D checkpoints): the units whose *_temporal* parameters differ from the identity

@@ -487,7 +487,7 @@ int UNet::finalize(hipStream_t s) {
         const WTensor& t = weights[k];
         if (t.shape.size() != 2 || t.shape[0] != t.shape[1] || !uv_attn2_fused_ok((int)t.shape[0], cfg.attention_heads[level_of(k)], 64, 77)) continue;
         const std::string wq = b + (find(b + ".attn2.to_q.weight#qs") ? ".attn2.to_q.weight#qs" : ".attn2.to_q.weight");
-        for (const std::string& src : {k, wq, wq + "#ln"}) {
+        for (const std::string& src : {k, wq, wq + "#ln", b + ".attn1.to_out.0.weight"}) {
             const WTensor* w = find(src);
             if (!w) continue;
             half_t* d;
@@ -1012,9 +1012,35 @@ struct Fwd {
         const bool t_attn = u.temporal_attn_active.count(b) != 0;
         RUN(linear(text, u.cfg.cross_attention_dim, (long)B * text_len, u.cfg.cross_attention_dim, b + ".attn2.kv#fused", "",
                    2 * C, kv, 2 * C));
+        // round 5, second step: the self-attention's out projection rides in FRONT of the fused text cross-attention (fused.hip, PRE): h2 = to_out(attn1) + h
+        // is that kernel's input and residual and nothing else reads it, so it stays in the block's LDS
+        const std::string wqf0 = wq2 + "#ln#frag", wof0 = b + ".attn2.to_out.0.weight#frag", wpf0 = b + ".attn1.to_out.0.weight#frag";
+        const bool a2pre = nbands == 1 && fold && u.attn2_fused > 1 && uv_attn2_fused_ok(C, heads, F * N, text_len) && u.find(wqf0) && u.find(wof0) && u.find(wpf0);
         for (int bd = 0; bd < nbands; ++bd) {
             const long r0 = (long)bd * brows, o = r0 * C;
             float* lb = lnst ? lnst + r0 * (C / 160) * 2 : nullptr;
+            if (a2pre) {
+                half_t* kvf = alloc(uv_attn2_kvf_halfs(B, heads, d));
+                if (!kvf || !(h3 = alloc(rows * C))) return UV_ERR_STATE;
+                RUN(uv_launch_kv_frag_pack(kv, kvf, B, text_len, C, heads, s));
+                Attn2Params a2;
+                a2.X = t0; a2.ldx = C; a2.M = (int)rows;
+                a2.Wp_f = W(wpf0); a2.bias_p = W(b + ".attn1.to_out.0.bias"); a2.Rp = h; a2.ldrp = C;
+                a2.ln_eps = 1e-5f; a2.ln_slots = C / 160;
+                a2.ln_wsum = (const float*)W(wq2 + "#ln.wsum"); a2.ln_bias = (const float*)W(wq2 + "#ln.bias");
+                a2.Wq_f = W(wqf0); a2.kvf = kvf;
+                a2.rows_per_branch = F * N; a2.heads = heads; a2.Nkv = text_len;
+                a2.q_prescaled = qs2; a2.scale_log2e = ap.scale_log2e;
+                a2.Wo_f = W(wof0); a2.bias_o = W(b + ".attn2.to_out.0.bias");
+                a2.Y = h3; a2.ldy = C;
+                a2.stats_out = fold3 ? lb : nullptr;
+                if (!a2.bias_p || !a2.bias_o || !a2.ln_wsum || !a2.ln_bias) return u.missing_error();
+                RUN(uv_launch_attn2_fused(a2, C, s));
+                free(kvf);
+                free(kv);
+                free(h);
+                free(h2);
+            } else {
             RUN(linear(t0 + o, C, brows, C, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", C, h2 + o, C, h + o, C, nullptr, 0, lb));
             if (nbands == 1) free(h);
             // ---- attn2 (text)
@@ -1060,6 +1086,7 @@ struct Fwd {
             if (!h3 && !(h3 = alloc(rows * C))) return UV_ERR_STATE;
             RUN(linear(t0 + o, C, brows, C, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", C, h3 + o, C, h2 + o, C, nullptr, 0, fold3 ? lb : nullptr));
             if (nbands == 1) free(h2);
+            }
             }
             if (!mid && !(mid = alloc(brows * 4 * C))) return UV_ERR_STATE;
             // ---- GEGLU feed-forward (+ the bias-only temporal attention, attention.py:233)
