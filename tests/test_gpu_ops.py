@@ -375,7 +375,7 @@ def prescaled(q, d):
 
 @pytest.mark.parametrize("heads,d,N,Fr,mode,pre", [(2, 40, 2048 + 40, 2, "stock", 1), (8, 40, 2304, 1, "pnp", 1), (2, 40, 2048 + 40, 2, "stock", 0),
                                                     (2, 16, 64, 3, "stock", 0), (2, 32, 256, 4, "pnp", 0), (8, 40, 576, 2, "stock", 0), (8, 40, 576, 2, "stock", 1),
-                                                    (8, 80, 128, 3, "pnp", 0), (8, 160, 64, 2, "stock", 0), (4, 64, 200, 2, "stock", 0)])
+                                                    (8, 80, 128, 3, "pnp", 0), (8, 160, 64, 2, "stock", 0), (8, 80, 1024, 3, "stock", 1), (4, 80, 512 + 40, 2, "pnp", 1), (4, 64, 200, 2, "stock", 0)])
 def test_attention_sparse_causal(nat, heads, d, N, Fr, mode, pre):
     """fused-QKV layout, K/V gathered by pointer from {prev, (cur), first} frames of the same branch.  pre: q carries
     log2(e)/sqrt(d) already (head_dim 40, Nq >= 2048 then runs the software-pipelined kernel)."""
@@ -513,10 +513,12 @@ def test_attention_d40_long_merged_sources_and_text(nat):
 
 
 # ---- the software-pipelined head_dim-64 kernel (prescaled q, Nq >= 1024): reference in the MFMA accumulator, dot2 row sums --------
-def test_attention_d64_long_reference_jumps(nat):
-    """the d = 40 kernel's torture cases at head_dim 64 (attn_pp64_kernel): late large positive excursions, strongly negative first
-    scores, ragged key count; the same inputs with plain q (generic body) for comparison."""
-    heads, d, N = 2, 64, 1024 + 200
+@pytest.mark.parametrize("d", [64, 80])
+def test_attention_d64_long_reference_jumps(nat, d):
+    """the d = 40 kernel's torture cases at head_dim 64 and 80 (attn_pp64_kernel<64, 4> / <80, 2>: the latter with a half-padded third k
+    step and 32 query rows per wave): late large positive excursions, strongly negative first scores, ragged key and query counts; the
+    same inputs with plain q (generic body) for comparison."""
+    heads, N = 2, 1024 + 200
     C = heads * d
     q, k, v = rnd(1, N, C, seed=1) * 2, rnd(1, N, C, seed=2), rnd(1, N, C, seed=3)
     k[0, 900] = q[0, 5] * 6
@@ -531,8 +533,9 @@ def test_attention_d64_long_reference_jumps(nat):
     close(nat.attention(q, k, v, src, heads), sdpa_ref(q, k, v, heads), rtol=4e-3)
 
 
-def test_attention_d64_long_merged_sources(nat):
-    heads, d, N = 4, 64, 1088
+@pytest.mark.parametrize("d", [64, 80])
+def test_attention_d64_long_merged_sources(nat, d):
+    heads, N = 4, 1088
     C = heads * d
     qkv = rnd(3, N, 3 * C, seed=1)
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]

@@ -950,6 +950,9 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 //   * 16 data planes per tile and stage (8 K + 8 V), four DMA instructions per wave and tile, no constant planes, no LDS init;
 //   * the EXTRA key segment of the joint attention (AttnParams::kx: the frame's text tokens, own length / stride / buffers,
 //     multiplicity 1) is one more source of the tile sequence.
+// D, QB (round 5): the same kernel at head_dim 80 (the 32x32 level of the SD-v1.5 UNet) with QB = 2 query blocks (32 rows) per wave: three 32-wide k
+// steps whose last half is padding (two K planes of a stage that are zeroed once and never written by the DMAs; Q is zero there), five V^T
+// fragments, 20 data planes per tile = five DMA instructions per wave; 23.25 KB per stage, 70 KB per block, two blocks per CU.
 // Register budget (2 waves per SIMD: 256): O^T 64 + two score sets 64 + Q 32 + cfold 16 + K / V / P fragments 48 + bookkeeping: 256, no
 // spill.  Measured (12 frames x 24 heads x 4096 queries over 3 x 4096 keys, same box): 3.85 ms = 963 TF against 4.23 ms = 878 TF of
 // attn_body<64, 4, 4>; with ONE wave per SIMD 6.79 ms (546 TF: the second wave hides the tile barrier and the LDS latency); without
@@ -957,17 +960,21 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 // per SIMD the step costs the SUM of its MFMA cycles (32 x 16 = 512) and its VALU / transcendental issue cycles (~450): the two do not
 // overlap across the two waves of a SIMD (tools/probes/coissue_probe.hip) and hardly inside one here.  What is left is less work per
 // key, not a better order.
-template <int TAG = 0>
+template <int D = 64, int QB = 4, int TAG = 0>
 __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
-    constexpr int NW = 4, D = 64, DV16 = 4, QB = 4, NST = 3, NPL = 8;
+    static_assert(D % 16 == 0 && D % 8 == 0 && (QB == 2 || QB == 4), "whole V^T fragments, 16-byte K / V chunks");
+    constexpr int NW = 4, DV16 = D / 16, NST = 3;
+    constexpr int KS = (D + 31) / 32;                        // 32-wide k steps of QK^T (D = 80: the third is half padding)
+    constexpr int NDK = D / 8, NPK = KS * 4, NPV = D / 8;    // data chunks of a K row, K planes of a stage (NPK - NDK zero planes), V planes
+    constexpr int RB = NW * 16 * QB;                         // query rows of a block
     constexpr int KPL = 512, VPL = 576;                      // plane strides in halfs (1024 B / 1152 B: see attn_pp40_kernel STG)
-    constexpr int KAREA = NPL * KPL;
-    constexpr int TILE = NPL * KPL + NPL * VPL;              // 17 KB per stage
+    constexpr int KAREA = NPK * KPL;
+    constexpr int TILE = NPK * KPL + NPV * VPL;              // 17 KB per stage (D = 64), 23.25 KB (D = 80)
     __shared__ __attribute__((aligned(16))) half_t smem[NST * TILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int nqb = (p.Nq + 64 * NW - 1) / (64 * NW);
+    const int nqb = (p.Nq + RB - 1) / RB;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int qblk = lid % nqb;
     const int h = p.order ? lid / (nqb * p.BF) : (lid / nqb) % p.heads;
@@ -984,13 +991,13 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
     auto seg_ntile = [&](int sidx) { return sidx < nsrc_eff ? ntile : ntile_x; };
 
     // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
-    h8 qf[QB][2];
+    h8 qf[QB][KS];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
+        const int qrow = qblk * RB + wave * 16 * QB + qb * 16 + l15;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            qf[qb][ks] = qrow < p.Nq ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + ks * 32 + g * 8) : zero8;
+        for (int ks = 0; ks < KS; ++ks)
+            qf[qb][ks] = (qrow < p.Nq && ks * 32 + g * 8 < D) ? *reinterpret_cast<const h8*>(p.q + ((long)bf * p.Nq + qrow) * p.ldq + h * D + ks * 32 + g * 8) : zero8;
     }
 
     f4 o[DV16][QB], cfold[QB];
@@ -1032,13 +1039,15 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
         const half_t* const ksrc = p.k + ld_koff + roff;
         const half_t* const vsrc = p.v + ld_voff + roff;
 #pragma unroll
-        for (int j = 0; j < 2 * NPL / NW; ++j) {
+        for (int j = 0; j < (NDK + NPV + NW - 1) / NW; ++j) {
             const int pl = wave_u + NW * j;                      // wave-uniform
-            const bool isv = pl >= NPL;
-            const int c = pl & (NPL - 1);
-            const half_t* src = rok ? (isv ? vsrc : ksrc) + c * 8 : zpage;
-            const int dst = stage_half + (isv ? KAREA + c * VPL : c * KPL);
-            glds16(src, __builtin_amdgcn_readfirstlane(smem_lds + 2u * (unsigned)dst));
+            if ((j + 1) * NW <= NDK + NPV || pl < NDK + NPV) {
+                const bool isv = pl >= NDK;
+                const int c = isv ? pl - NDK : pl;
+                const half_t* src = rok ? (isv ? vsrc : ksrc) + c * 8 : zpage;
+                const int dst = stage_half + (isv ? KAREA + c * VPL : c * KPL);
+                glds16(src, __builtin_amdgcn_readfirstlane(smem_lds + 2u * (unsigned)dst));
+            }
         }
         if (++ld_t == ld_ntile) {
             ld_t = 0;
@@ -1056,11 +1065,11 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
     // ---- the pipeline pieces
     const int kf_off = g * KPL + l15 * 8;
     const int vf_off = KAREA + ((l15 & 3) >> 1) * VPL + (g * 4 + (l15 >> 2)) * 8 + (l15 & 1) * 4;
-    auto kfrag_read = [&](const half_t* st, int hh, h8 (&kf)[2][2]) {
+    auto kfrag_read = [&](const half_t* st, int hh, h8 (&kf)[2][KS]) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (hh * 32 + kb * 16) * 8 + ks * 4 * KPL]);
+            for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *reinterpret_cast<const h8*>(&st[kf_off + (hh * 32 + kb * 16) * 8 + ks * 4 * KPL]);
     };
     auto vfrag_read = [&](const half_t* st, int hh, h8 (&vf)[DV16]) {
 #pragma unroll
@@ -1074,15 +1083,17 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
             vf[dv] = a;
         }
     };
-    auto qk = [&](const h8 (&kf)[2][2], f4 (&sc)[2][QB]) {        // S^T - M + lw of one 32-key step: 16 MFMAs, the first eight start from cfold
+    auto qk = [&](const h8 (&kf)[2][KS], f4 (&sc)[2][QB]) {       // S^T - M + lw of one 32-key step: 2 KS QB MFMAs, the first 2 QB start from cfold
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], cfold[qb], 0, 0, 0);
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int ks = 1; ks < KS; ++ks)
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], sc[kb][qb], 0, 0, 0);
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][ks], qf[qb][ks], sc[kb][qb], 0, 0, 0);
     };
     auto exp_part = [&](const f4 (&sc)[2][QB], h8 (&pb)[QB]) {    // P^T (fp16, B operand of the PV MFMA)
 #pragma unroll
@@ -1137,7 +1148,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
     // and cfold takes the new reference for every later step.
     auto decide = [&](f4 (&sc)[2][QB], const float (&mx)[QB], float lw, bool first) {
         if (!first) {
-            const float mall = fmaxf(max3f(mx[0], mx[1], mx[2]), mx[3]);
+            const float mall = QB == 4 ? fmaxf(max3f(mx[0], mx[1], mx[2]), mx[QB - 1]) : fmaxf(mx[0], mx[1]);
             if (__builtin_amdgcn_ballot_w64(mall > DEFER) == 0) return;
         }
 #pragma unroll
@@ -1175,21 +1186,29 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
         }
     };
 // issue order inside the two overlapped regions (LLVM SchedGroupMask: VALU 0x2, MFMA 0x8, DS read 0x100, TRANS 0x400)
+/* phase 1: 2 KS QB QK^T MFMAs over 2 DV16 V fragment reads, 8 QB exponentials and 4 QB conversions; phase 2: DV16 QB PV MFMAs over 2 KS K fragment */ \
+/* reads and 8 QB max3 / dot2 (D = 64, QB = 4: 16 | 8, 32, 16 and 16 | 4, 32 — the round-3 pattern) */ \
 #define UV_P64_PHASE1()                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2 * KS * QB; ++i_) {                  \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
-        if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
-        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                        \
-        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        \
+        if (i_ < 2 * DV16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     \
+        if (i_ < 4 * QB) {                                                        \
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                    \
+        }                                                                         \
     }
 #define UV_P64_PHASE2()                                                           \
-    _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                           \
+    _Pragma("unroll") for (int i_ = 0; i_ < DV16 * QB; ++i_) {                    \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
-        if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            \
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                        \
+        if (i_ < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       \
+        if (i_ < 4 * QB) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);       \
     }
-#define UV_P64_PIN4(a) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]))
+#define UV_P64_PIN4(a) do { if constexpr (QB == 4) asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); else asm volatile("" : "+v"(a[0]), "+v"(a[1])); } while (0)
 
+    if constexpr (NPK > NDK) {      // the padding planes of K (columns D .. 32 KS - 1) are zero for the whole launch: the DMAs never write them
+        for (int i = tid * 8; i < NST * TILE; i += NW * 64 * 8) *reinterpret_cast<h8*>(&smem[i]) = zero8;
+        __syncthreads();
+    }
     // ---- prologue: tiles 0 and 1 into the ring, scores + reference of step (0, 0)
     dma_tile(0);
     if (T > 1) dma_tile(TILE);
@@ -1197,7 +1216,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
     __syncthreads();
 
     f4 scA[2][QB], scB[2][QB];
-    h8 kf[2][2], vf[DV16], pb[QB];
+    h8 kf[2][KS], vf[DV16], pb[QB];
     float mx[QB];
     int cs_s = 0, cs_t = 0;                                  // (segment, tile in segment) of tile tt
     int nkv_cur = seg_nkv(0), nkv_nxt = nkv_cur;
@@ -1283,7 +1302,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.f / l;
-        const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
+        const int qrow = qblk * RB + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
 #pragma unroll
@@ -1513,7 +1532,21 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         // generic body: SD3.5 step 944 / 947 -> 934 / 943 ms, same box; 1 = image queries only)
         if (pp64 && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && p.kx && p.Nq >= 192))) {
             const int nqb4 = (p.Nq + 255) / 256;
-            hipLaunchKernelGGL((attn_pp64_kernel<0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((attn_pp64_kernel<64, 4, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    if constexpr (DPAD == 96 && DV16 == 5) {
+        // head_dim 80 (the 32x32 level of SD-v1.5) with prescaled q: the same pipeline at 32 query rows per wave (round 5).  It issues half the VALU
+        // work per score of the generic body (no scale fma, dot2 row sums, deferred rescale) but runs two waves per SIMD where attn_kernel_occ3 runs
+        // three, and with 44 MFMAs per wave between two tile barriers the third wave hides more than the leaner stream saves: same box, alternating,
+        // the 32x32-level attention of the full step 2.18 -> 2.27 ms (slower), of a rank's shard (384 blocks: less than one round of the chip) 0.435 ->
+        // 0.404 ms (faster).  So it serves grids of at most one round (2 blocks per CU); UNIVST_ATTN_PP80 = 0 never, 2 always (A/B aid)
+        static const int pp80 = getenv("UNIVST_ATTN_PP80") ? atoi(getenv("UNIVST_ATTN_PP80")) : 1;
+        const int nqb2 = (p.Nq + 127) / 128;
+        if (pp80 && p.q_prescaled && !p.kx && p.Nq >= 512 && (pp80 == 2 || (long)nqb2 * p.heads * p.BF <= 512)) {
+            hipLaunchKernelGGL((attn_pp64_kernel<80, 2, 0>), dim3(nqb2 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
             return UV_OK;
         }
