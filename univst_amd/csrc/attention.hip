@@ -33,7 +33,11 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     return r;
 }
 
-template <int DPAD, int DV16, int QB>
+// CF (round 5; prescaled q only, the wide heads without a spare V column): the running reference enters as the ACCUMULATOR of the first QK^T MFMA
+// (cf[qb] = lw - mrun, what attn_pp64_kernel calls cfold), so the per-score scale fma disappears; the rare reference change shifts the pending scores.
+// Without ONES the row sums are taken from the PACKED fp16 probabilities with v_dot2 (one VALU op per two keys, and the denominator is the sum of exactly
+// the values the PV MFMA multiplies).  ISA count per 64 keys x 32 queries at head_dim 80: 198 -> ~150 VALU issue slots.
+template <int DPAD, int DV16, int QB, bool CF = false>
 __device__ __forceinline__ void attn_body(const AttnParams& p) {
     constexpr int KSTR = lds_stride_bytes(DPAD * 2) / 2;
     constexpr int DV = DV16 * 16;
@@ -73,9 +77,11 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
 
     f4 o[DV16][QB];
     float mrun[QB], lrun[QB];      // running max in RAW score units; lrun unused when ONES
+    float cf[QB];                  // CF: lw - mrun, the accumulator the scores start from
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
-        mrun[qb] = -INFINITY;
+        mrun[qb] = CF ? 0.f : -INFINITY;
+        cf[qb] = 0.f;
         lrun[qb] = 0.f;
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) o[dv][qb] = f4{0.f, 0.f, 0.f, 0.f};
@@ -177,6 +183,10 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     int cur_nkv = p.Nkv, cur_ntile = ntile;
     float lw = p.src_logw ? p.src_logw[bf * p.nsrc] : 0.f;            // log2 multiplicity of the current source ...
     float lwr = lw * (1.f / c);                                       // ... in raw-score units
+    if (CF) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) cf[qb] = lw;
+    }
     for (int tt = 0; tt < T; ++tt) {
         half_t* Ks = smem + (DBUF ? (tt & 1) * TILE : 0);
         half_t* Vs = Ks + KT * KSTR;
@@ -188,7 +198,7 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = f4{0.f, 0.f, 0.f, 0.f};
+            for (int qb = 0; qb < QB; ++qb) sc[kb][qb] = CF ? f4{cf[qb], cf[qb], cf[qb], cf[qb]} : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -225,6 +235,47 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
             // rescale + its accumulator traffic is skipped for the whole wave.  mrun is uniform over the 4 lane groups of a
             // query column, so "row max exceeds the bound" == "some lane's local max does": the cross-lane reduction (two
             // LDS-crossbar permutes + waits) is only paid inside the rare branch.
+            if constexpr (CF) {
+                // the scores already are s - mrun + lw: the deferred test is on them directly.  The first tile sets the reference whatever its
+                // sign (a strongly negative first row max would underflow every probability); later changes only raise it.
+                if (__builtin_amdgcn_ballot_w64(tt == 0 || mx > DEFER) != 0) {
+                    const float o16 = __shfl_xor(mx, 16, 64);
+                    mx = max3f(mx, o16, o16);
+                    const float o32 = __shfl_xor(mx, 32, 64);
+                    mx = max3f(mx, o32, o32);
+                    float delta = tt == 0 ? mx : fmaxf(mx, 0.f);                    // row max (incl. the source's log2 multiplicity) above the current reference
+                    if (!(delta > -3.0e38f)) delta = 0.f;                           // a fully masked first tile (-inf): keep the reference
+                    mrun[qb] += delta;
+                    cf[qb] = lw - mrun[qb];
+                    const float alpha = tt == 0 ? 1.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        sc[kb][qb][0] -= delta; sc[kb][qb][1] -= delta; sc[kb][qb][2] -= delta; sc[kb][qb][3] -= delta;
+                    }
+#pragma unroll
+                    for (int dv = 0; dv < DV16; ++dv) {
+                        o[dv][qb][0] *= alpha; o[dv][qb][1] *= alpha; o[dv][qb][2] *= alpha; o[dv][qb][3] *= alpha;
+                    }
+                    lrun[qb] *= alpha;
+                }
+                union { fh2 h[4]; h8 v; } u0, u1;
+                const fh2 one2 = {(__fp16)1.f, (__fp16)1.f};
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const float e0 = __builtin_amdgcn_exp2f(sc[kb][qb][0]), e1 = __builtin_amdgcn_exp2f(sc[kb][qb][1]);
+                    const float e2 = __builtin_amdgcn_exp2f(sc[kb][qb][2]), e3 = __builtin_amdgcn_exp2f(sc[kb][qb][3]);
+                    const fh2 lo = __builtin_amdgcn_cvt_pkrtz(e0, e1), hi = __builtin_amdgcn_cvt_pkrtz(e2, e3);
+                    if (!ONES) {
+                        lrun[qb] = __builtin_amdgcn_fdot2(lo, one2, lrun[qb], false);
+                        lrun[qb] = __builtin_amdgcn_fdot2(hi, one2, lrun[qb], false);
+                    }
+                    if (kb < 2) { u0.h[(kb & 1) * 2] = lo; u0.h[(kb & 1) * 2 + 1] = hi; }
+                    else { u1.h[(kb & 1) * 2] = lo; u1.h[(kb & 1) * 2 + 1] = hi; }
+                }
+                pb[qb][0] = u0.v;
+                pb[qb][1] = u1.v;
+                continue;
+            }
             mx += lwr;
             float alpha = 1.f;
             if (__builtin_amdgcn_ballot_w64((mx - mrun[qb]) * c > DEFER) != 0) {
@@ -301,6 +352,10 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
                 lw = 0.f;
                 lwr = 0.f;
             }
+            if (CF) {
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) cf[qb] = lw - mrun[qb];
+            }
         }
     }
 
@@ -333,15 +388,15 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     }
 }
 
-template <int DPAD, int DV16, int QB>
+template <int DPAD, int DV16, int QB, bool CF = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
-    attn_body<DPAD, DV16, QB>(p);
+    attn_body<DPAD, DV16, QB, CF>(p);
 }
 // same body, register budget capped for 3 waves per SIMD (the small-head-dim kernels are VALU/latency bound:
 // one more resident wave per SIMD hides the softmax behind another wave's MFMAs)
-template <int DPAD, int DV16, int QB>
+template <int DPAD, int DV16, int QB, bool CF = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
-    attn_body<DPAD, DV16, QB>(p);
+    attn_body<DPAD, DV16, QB, CF>(p);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -1562,6 +1617,22 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     const int QB = p.Nq >= 512 ? 2 : 1;
     const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
     dim3 grid(nqb * p.heads * p.BF), block(256);
+    if constexpr (DPAD >= 96) {
+        // prescaled q on the wide heads (80, 160: the 32x32 / 16x16 levels of SD-v1.5): the reference rides in the MFMA accumulator, row sums by
+        // v_dot2 (attn_body CF).  UNIVST_ATTN_CF=0 (A/B aid): the plain softmax arithmetic
+        static const int cfenv = getenv("UNIVST_ATTN_CF") ? atoi(getenv("UNIVST_ATTN_CF")) : 1;
+        if (cfenv && p.q_prescaled) {
+            if constexpr (DPAD == 96) {
+                if (QB == 2) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, true>), grid, block, 0, stream, p);
+            } else {
+                if (QB == 2) hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, true>), grid, block, 0, stream, p);
+            }
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
     if constexpr (DPAD <= 96) {           // (not instantiated for wider heads: at 168 VGPRs they spill, and a spilled prefetch
         if (QB == 2) {                    //  register is read before its asm load has landed — tests/test_asm_hazards.py)
             hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2>), grid, block, 0, stream, p);

@@ -405,7 +405,7 @@ int UNet::finalize(hipStream_t s) {
             UV_HIP(hipMemcpyAsync(d + C * K, tk->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
             UV_HIP(hipMemcpyAsync(d + 2 * C * K, tv->ptr, C * K * 2, hipMemcpyDeviceToDevice, s));
             const int hd = (int)C / cfg.attention_heads[level_of(k)];
-            if (hd == 40 || hd == 64 || hd == 80) {         // second copy whose Q rows carry log2(e)/sqrt(d) (AttnParams::q_prescaled): the software-
+            if (hd == 40 || hd == 64 || hd == 80 || hd == 160) {         // second copy whose Q rows carry log2(e)/sqrt(d) (AttnParams::q_prescaled): the software-
                 half_t* d2;                     // pipelined kernels (head_dim 40: SD-v1.5; 64: the SD-v2.1 layout) take the scale from the weights
                 rc = derive_alloc(p + "qkv#fused#qs", {3 * C, K}, &d2);
                 if (rc) return rc;
