@@ -1593,12 +1593,12 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         }
     }
     if constexpr (DPAD == 96 && DV16 == 5) {
-        // head_dim 80 (the 32x32 level of SD-v1.5) with prescaled q: the same pipeline at 32 query rows per wave (round 5).  It issues half the VALU
-        // work per score of the generic body (no scale fma, dot2 row sums, deferred rescale) but runs two waves per SIMD where attn_kernel_occ3 runs
-        // three, and with 44 MFMAs per wave between two tile barriers the third wave hides more than the leaner stream saves: same box, alternating,
-        // the 32x32-level attention of the full step 2.18 -> 2.27 ms (slower), of a rank's shard (384 blocks: less than one round of the chip) 0.435 ->
-        // 0.404 ms (faster).  So it serves grids of at most one round (2 blocks per CU); UNIVST_ATTN_PP80 = 0 never, 2 always (A/B aid)
-        static const int pp80 = getenv("UNIVST_ATTN_PP80") ? atoi(getenv("UNIVST_ATTN_PP80")) : 1;
+        // head_dim 80 (the 32x32 level of SD-v1.5) with prescaled q: the same pipeline at 32 query rows per wave (round 5) — measured and NOT
+        // dispatched by default.  It runs two waves per SIMD where attn_kernel_occ3 runs three, and with 44 MFMAs per wave between two tile
+        // barriers the third wave hides more than the leaner instruction stream saves: same box, alternating, the 32x32-level attention of the
+        // full step 2.18 -> 2.27 ms; of a rank's shard (384 blocks) 0.435 -> 0.404 ms — and the generic body with the same arithmetic savings
+        // (attn_body CF, built right after) takes 1.86 ms / 0.364 ms.  UNIVST_ATTN_PP80 = 1: grids of at most one round, 2: always (A/B aid)
+        static const int pp80 = getenv("UNIVST_ATTN_PP80") ? atoi(getenv("UNIVST_ATTN_PP80")) : 0;
         const int nqb2 = (p.Nq + 127) / 128;
         if (pp80 && p.q_prescaled && !p.kx && p.Nq >= 512 && (pp80 == 2 || (long)nqb2 * p.heads * p.BF <= 512)) {
             hipLaunchKernelGGL((attn_pp64_kernel<80, 2, 0>), dim3(nqb2 * p.heads * p.BF), dim3(256), 0, stream, p);
