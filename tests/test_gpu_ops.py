@@ -554,6 +554,17 @@ def test_attention_d64_long_merged_sources(nat, d):
     close(got2, ref, rtol=4e-3)
 
 
+def test_attention_d80_pipelined_kernel_forced():
+    """attn_pp64_kernel<80, 2> is not dispatched by default (the generic body with the folded reference is faster); the switch is read
+    once per process, so its parity cases run in a child process with UNIVST_ATTN_PP80=2."""
+    import os, subprocess, sys
+    env = dict(os.environ, UNIVST_ATTN_PP80="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-x", "-k", "(d64_long and 80) or (sparse_causal and 80)",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("C,N,Fr,idx", [(64, 64, 4, 0), (320, 256, 3, 13), (1280, 64, 2, 25)])
 def test_attention_adain_shift(nat, C, N, Fr, idx):
     qkv = (rnd(3 * Fr * N, 3 * C, seed=1) * 1.5 + 0.2)

@@ -1606,6 +1606,16 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
             return UV_OK;
         }
     }
+    // (probe, round 5) UNIVST_ATTN_CF40=1 with UNIVST_ATTN_PP=0: head_dim 40 on the generic body with the accumulator-folded reference at three waves per SIMD
+    static const int cf40 = getenv("UNIVST_ATTN_CF40") ? atoi(getenv("UNIVST_ATTN_CF40")) : 0;
+    if constexpr (DPAD == 64 && DV16 == 3) {
+        if (cf40 && p.q_prescaled && p.Nq >= 512) {
+            const int nqb2 = (p.Nq + 127) / 128;
+            hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, true>), dim3(nqb2 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
     if constexpr (DPAD <= 64) {
         if (qb4 && p.Nq >= 2048) {
             const int nqb4 = (p.Nq + 255) / 256;
