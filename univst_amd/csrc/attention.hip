@@ -1608,6 +1608,15 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
     }
     // (probe, round 5) UNIVST_ATTN_CF40=1 with UNIVST_ATTN_PP=0: head_dim 40 on the generic body with the accumulator-folded reference at three waves per SIMD
     static const int cf40 = getenv("UNIVST_ATTN_CF40") ? atoi(getenv("UNIVST_ATTN_CF40")) : 0;
+    if constexpr (DPAD == 64 && DV16 == 4) {      // (probe) UNIVST_ATTN_CF64=1 with UNIVST_ATTN_PP64=0: the same at head_dim 64 (SD3 joint attention, SD-v2.1)
+        static const int cf64 = getenv("UNIVST_ATTN_CF64") ? atoi(getenv("UNIVST_ATTN_CF64")) : 0;
+        if (cf64 && p.q_prescaled && p.Nq >= 192) {
+            const int nqb2 = (p.Nq + 127) / 128;
+            hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, true>), dim3(nqb2 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
     if constexpr (DPAD == 64 && DV16 == 3) {
         if (cf40 && p.q_prescaled && p.Nq >= 512) {
             const int nqb2 = (p.Nq + 127) / 128;
