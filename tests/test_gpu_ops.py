@@ -375,7 +375,7 @@ def prescaled(q, d):
 
 @pytest.mark.parametrize("heads,d,N,Fr,mode,pre", [(2, 40, 2048 + 40, 2, "stock", 1), (8, 40, 2304, 1, "pnp", 1), (2, 40, 2048 + 40, 2, "stock", 0),
                                                     (2, 16, 64, 3, "stock", 0), (2, 32, 256, 4, "pnp", 0), (8, 40, 576, 2, "stock", 0), (8, 40, 576, 2, "stock", 1),
-                                                    (8, 80, 128, 3, "pnp", 0), (8, 160, 64, 2, "stock", 0), (8, 80, 1024, 3, "stock", 1), (4, 80, 512 + 40, 2, "pnp", 1), (4, 64, 200, 2, "stock", 0)])
+                                                    (8, 80, 128, 3, "pnp", 0), (8, 160, 64, 2, "stock", 0), (8, 80, 1024, 3, "stock", 1), (4, 80, 512 + 40, 2, "pnp", 1), (4, 160, 256, 2, "stock", 1), (2, 160, 640, 2, "pnp", 1), (4, 80, 200, 3, "stock", 1), (4, 64, 200, 2, "stock", 0)])
 def test_attention_sparse_causal(nat, heads, d, N, Fr, mode, pre):
     """fused-QKV layout, K/V gathered by pointer from {prev, (cur), first} frames of the same branch.  pre: q carries
     log2(e)/sqrt(d) already (head_dim 40, Nq >= 2048 then runs the software-pipelined kernel)."""
