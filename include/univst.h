@@ -256,6 +256,16 @@ int univst_layernorm(const void* X, void* Y, const void* gamma, const void* beta
 int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
                      const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv,
                      int heads, int head_dim, int q_prescaled, void* stream);
+/* the same attention with the key set of a query split over TWO launches (round 6: a rank of the frame shard consumes the key frames it holds while the
+ * halo frames of attention.py:384-413 / pnp_utils.py:59-84 are still on the wire; online softmax does not depend on the order of the keys).
+ *   phase 1: state_out != NULL, state_in == NULL — rows of `out` normalised over this launch's sources, state_out[((bf*heads + h)*Nq + i)*2] = (m, l):
+ *            the reference of the exponentials in log2 units and the denominator w.r.t. it; a frame with src_cnt[bf] == 0 gets zero rows and l = 0;
+ *   phase 2: state_in = phase 1's state_out, `out` = phase 1's rows (read-modify-write): out <- softmax over the UNION of both launches' sources —
+ *            exact up to the fp16 rounding of the phase-1 rows; frames with src_cnt[bf] == 0 keep their phase-1 rows.
+ * src_cnt is required.  Served at every head_dim of univst_attention. */
+int univst_attention_phase(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
+                           const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv,
+                           int heads, int head_dim, int q_prescaled, float* state_out, const float* state_in, void* stream);
 /* ---- first vertical slice of the SD3 / SD3.5 rectified-flow path (the reference-owned pieces only) ----
  * The joint-attention processors of backbones/video_diffusion_sd3/pnp_utils.py: CrossFrameProcessor (:17-131; shift = 0) and
  * AttentionShiftProcessor (:143-271; shift = 1 applies the AdaIN shift with alpha 0.8 / gamma 2.0 and the given beta.  The window test

@@ -400,6 +400,63 @@ def test_attention_sparse_causal(nat, heads, d, N, Fr, mode, pre):
     close(got, ref, rtol=4e-3)
 
 
+@pytest.mark.parametrize("heads,d,N,Fl,mode,pre", [(8, 40, 2048 + 40, 2, "stock", 1), (8, 40, 2304, 2, "pnp", 1), (2, 40, 2048, 4, "pnp", 1), (8, 40, 576, 2, "stock", 0),
+                                                    (4, 80, 1024, 2, "stock", 1), (4, 80, 512 + 40, 4, "pnp", 1), (4, 80, 200, 2, "pnp", 0), (4, 160, 256, 2, "stock", 1),
+                                                    (2, 160, 64, 4, "pnp", 1), (2, 160, 640, 2, "pnp", 0), (4, 64, 200, 2, "stock", 0), (2, 32, 256, 1, "pnp", 0)])
+def test_attention_two_phase_local_then_halo(nat, heads, d, N, Fl, mode, pre):
+    """TWO-PHASE attention (univst_attention_phase; round 6): a rank of the frame shard holds Fl frames per branch plus two halo frames per branch (the frame
+    before its first one and the clip's frame 0).  Launch 1 consumes the key frames the rank holds and leaves (m, l) per query; launch 2 continues over the
+    halo frames and merges.  Against the oracle's gather + SDPA over the FULL key set of attention.py:384-413 (stock: [-1, 0, 'first']) / pnp_utils.py:59-84
+    (PnP: [-1, 'first'] — the first local frame then has NO local source: phase 1 leaves it empty), both source tables, head_dim 40 (pipelined kernel from
+    2048 queries on) / 80 / 160 / 64 / 32, Fl = 1, 2 and 4 local frames, a spiky halo frame (the merge must rescale the local part)."""
+    B, C = 3, heads * d
+    # a clip of Fl + 2 frames per branch stands in for (first, ..., prev | local frames): clip frame 0 = 'first', frame 1 = prev of the first local frame
+    Fc = Fl + 2
+    qkv = rnd(B * Fc, N, 3 * C, seed=7)
+    qkv[Fc + 1, :, C:2 * C] *= 2.5                    # branch 1's halo (prev) frame: peaked scores in the second phase
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    qref = q
+    if pre:
+        qp, qref = prescaled(q, d)
+        qkv[..., :C] = qp
+    # reference: the reference's own index list on the clip (frame, 'first' = clip frame 0), rows of the local frames only
+    index = [-1, 0, "first"] if mode == "stock" else [-1, "first"]
+    kk = unet_ref.sparse_causal_gather(k.float().contiguous().cpu(), Fc, index).cuda()
+    vv = unet_ref.sparse_causal_gather(v.float().contiguous().cpu(), Fc, index).cuda()
+    ref = sdpa_ref(qref.contiguous(), kk, vv, heads).view(B, Fc, N, C)[:, 2:].reshape(B * Fl, N, C)
+    # the rank's buffers: local frames first, then [B prev | B first] halo frames (the UNet graph's layout)
+    view = qkv.view(B, Fc, N, 3 * C)
+    buf = torch.cat([view[:, 2:].reshape(B * Fl, N, 3 * C), view[:, 1], view[:, 0]]).contiguous()
+    ql, kl, vl = buf[..., :C], buf[..., C:2 * C], buf[..., 2 * C:]
+    loc, rem, c1, c2 = [], [], [], []
+    for b in range(B):
+        for f in range(Fl):
+            prev_halo, first_halo = B * Fl + b, B * Fl + B + b
+            if mode == "stock":
+                l_ = [b * Fl + f] if f == 0 else [b * Fl + f - 1, b * Fl + f]
+            else:
+                l_ = [] if f == 0 else [b * Fl + f - 1]
+            r_ = [prev_halo, first_halo] if f == 0 else [first_halo]
+            c1.append(len(l_)); c2.append(len(r_))
+            loc.append((l_ + [0, 0])[:2]); rem.append((r_ + [0, 0])[:2])
+    loc, rem = torch.tensor(loc, dtype=torch.int32).cuda(), torch.tensor(rem, dtype=torch.int32).cuda()
+    c1, c2 = torch.tensor(c1, dtype=torch.int32).cuda(), torch.tensor(c2, dtype=torch.int32).cuda()
+    qq = ql[:B * Fl]
+    out, st = nat.attention_phase(qq, kl, vl, loc, c1, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, q_prescaled=bool(pre))
+    if mode == "pnp":          # the first local frame of every branch had no local source: empty phase
+        assert float(st.view(B, Fl, heads, N, 2)[:, 0, :, :, 1].abs().max()) == 0.0 and float(out.view(B, Fl, N, C)[:, 0].abs().max()) == 0.0
+    got = nat.attention_phase(qq, kl, vl, rem, c2, heads, out=out, state_in=st, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, q_prescaled=bool(pre))
+    close(got, ref, rtol=4e-3)
+    # and the split is invisible: one launch over the union of the sources gives the same rows up to the fp16 rounding of the phase-1 rows
+    rows, cnt = [], []
+    for i in range(B * Fl):
+        u = loc[i, :int(c1[i])].tolist() + rem[i, :int(c2[i])].tolist()
+        cnt.append(len(u)); rows.append((u + [0] * 4)[:4])
+    one = nat.attention(qq, kl, vl, torch.tensor(rows, dtype=torch.int32).cuda(), heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C,
+                        src_cnt=torch.tensor(cnt, dtype=torch.int32).cuda(), q_prescaled=bool(pre))
+    close(got, one, rtol=2e-3)
+
+
 def test_attention_merged_duplicate_sources(nat):
     """a source listed m times == the source once with log2(m) added to its scores (what the UNet graph does for the
     duplicated frame 0 at f = 0, 1)."""

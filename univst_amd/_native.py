@@ -90,6 +90,7 @@ SIGNATURES = {
     "univst_groupnorm_nhwc": (_I, [_P, _P, _I, _I, _L, _I, _I, _F, _P, _P, _I, _P, _P, _P]),
     "univst_layernorm": (_I, [_P, _P, _P, _P, _L, _I, _F, _P]),
     "univst_attention": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "univst_attention_phase": (_I, [_P, _L, _P, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "univst_sd3_joint_attention": (_I, [C.POINTER(Sd3AttnWeights), _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P,
                                         C.POINTER(Sd3GatedResidual), _P, _P]),
     "univst_sd3_adain_shift": (_I, [_P, _L, _I, _I, _I, _I, _F, _F, _F, _P, _P]),
@@ -367,6 +368,23 @@ def attention(q, k, v, src_idx, heads, ldq=None, ldkv=None, Nq=None, Nkv=None, C
                                   ptr(src_idx), ptr(src_cnt), ptr(src_logw), src_idx.shape[1], BF, Nq_, Nkv or k.shape[1], heads, C_ // heads,
                                   int(bool(q_prescaled)), stream_ptr()), "attention")
     return out
+
+
+def attention_phase(q, k, v, src_idx, src_cnt, heads, out=None, state_out=None, state_in=None, ldq=None, ldkv=None, Nq=None, Nkv=None, C_=None, src_logw=None,
+                    q_prescaled=False):
+    """one launch of a TWO-PHASE attention (include/univst.h univst_attention_phase): phase 1 returns (out, state) with state [BF, heads, Nq, 2] fp32;
+    phase 2 takes them (state_in=, out=) and returns the merged rows in `out`."""
+    BF, Nq_, Cq = q.shape[0], (Nq or q.shape[1]), q.shape[2]
+    C_ = C_ or Cq
+    if out is None:
+        out = torch.empty(BF, Nq_, C_, device=q.device, dtype=torch.float16)
+    first = state_in is None
+    if first and state_out is None:
+        state_out = torch.empty(BF, heads, Nq_, 2, device=q.device, dtype=torch.float32)
+    check(load().univst_attention_phase(ptr(q), ldq or q.stride(1), ptr(k), ptr(v), ldkv or k.stride(1), ptr(out), C_,
+                                        ptr(src_idx), ptr(src_cnt), ptr(src_logw), src_idx.shape[1], BF, Nq_, Nkv or k.shape[1], heads, C_ // heads,
+                                        int(bool(q_prescaled)), ptr(state_out) if first else None, None if first else ptr(state_in), stream_ptr()), "attention_phase")
+    return (out, state_out) if first else out
 
 
 _SD3_KEYS = {"to_q": "to_q.weight", "to_q_bias": "to_q.bias", "to_k": "to_k.weight", "to_k_bias": "to_k.bias", "to_v": "to_v.weight",

@@ -344,6 +344,22 @@ int univst_attention(const void* q, int64_t ldq, const void* k, const void* v, i
     a.q_prescaled = q_prescaled != 0;
     return uv_launch_attention(a, S(s));
 }
+int univst_attention_phase(const void* q, int64_t ldq, const void* k, const void* v, int64_t ldkv, void* out, int64_t ldo,
+                           const int32_t* src_idx, const int32_t* src_cnt, const float* src_logw, int nsrc, int BF, int Nq, int Nkv, int heads,
+                           int d, int q_prescaled, float* state_out, const float* state_in, void* s) {
+    UV_REQUIRE(q && k && v && out && src_idx && src_cnt, "attention_phase: null argument (src_cnt is required: a phase may leave a frame without sources)");
+    UV_REQUIRE((state_out != nullptr) != (state_in != nullptr), "attention_phase: exactly one of state_out (first phase) / state_in (second phase)");
+    AttnParams a;
+    a.src_cnt = src_cnt;
+    a.src_logw = src_logw;
+    a.q = H(q); a.k = H(k); a.v = H(v); a.o = HM(out); a.ldq = ldq; a.ldkv = ldkv; a.ldo = ldo; a.src_idx = src_idx; a.nsrc = nsrc;
+    a.BF = BF; a.Nq = Nq; a.Nkv = Nkv; a.heads = heads; a.d = d;
+    a.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
+    a.q_prescaled = q_prescaled != 0;
+    a.state_out = state_out;
+    a.state_in = state_in;
+    return uv_launch_attention(a, S(s));
+}
 int univst_attention_adain_shift(void* qkv, int64_t ld, int F, int N, int C, float alpha, float beta, float gamma, void* ws, void* s) {
     UV_REQUIRE(qkv && ws, "adain_shift: null argument");
     float* w = (float*)ws;

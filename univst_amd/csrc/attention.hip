@@ -33,11 +33,41 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     return r;
 }
 
+// Two-phase attention (AttnParams::state_out / state_in): weights of the merge o = o1 * w1 + acc2 * w2, where o1 are the NORMALISED rows of the first
+// phase with state (m1, l1) and acc2 the unnormalised accumulator of this launch with reference m2 and denominator l2 (log2 units).  l == 0 marks an
+// empty phase.
+__device__ __forceinline__ void attn_merge_coef(float m1, float l1, float m2, float l2, float& w1, float& w2) {
+    const bool has1 = l1 > 0.f, has2 = l2 > 0.f;
+    const float m = has1 ? (has2 ? fmaxf(m1, m2) : m1) : m2;
+    const float a1 = has1 ? l1 * __builtin_amdgcn_exp2f(m1 - m) : 0.f;
+    const float a2 = has2 ? __builtin_amdgcn_exp2f(m2 - m) : 0.f;
+    const float den = a1 + l2 * a2;
+    const float inv = den > 0.f ? 1.f / den : 0.f;
+    w1 = a1 * inv;
+    w2 = a2 * inv;
+}
+// a (frame, head, query block) without any key source in this phase (src_cnt == 0: e.g. the first local frame of a rank in the local phase of a PnP layer,
+// whose two sources are both remote): phase 1 leaves zero rows with l = 0, phase 2 keeps what phase 1 wrote.  Block-uniform.
+template <int RB>
+__device__ __forceinline__ void attn_empty_phase(const AttnParams& p, int bf, int h, int qblk, int d) {
+    if (p.state_in || !p.state_out) return;
+    const int tid = threadIdx.x;
+    const int dch = d / 4;
+    for (int i = tid; i < RB * dch; i += 256) {
+        const int r = i / dch, c = i - r * dch, qrow = qblk * RB + r;
+        if (qrow < p.Nq) *reinterpret_cast<h4*>(p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * d + c * 4) = h4{0, 0, 0, 0};
+    }
+    for (int r = tid; r < RB; r += 256) {
+        const int qrow = qblk * RB + r;
+        if (qrow < p.Nq) *reinterpret_cast<float2*>(p.state_out + (((long)bf * p.heads + h) * p.Nq + qrow) * 2) = make_float2(0.f, 0.f);
+    }
+}
+
 // CF (round 5; prescaled q only, the wide heads without a spare V column): the running reference enters as the ACCUMULATOR of the first QK^T MFMA
 // (cf[qb] = lw - mrun, what attn_pp64_kernel calls cfold), so the per-score scale fma disappears; the rare reference change shifts the pending scores.
 // Without ONES the row sums are taken from the PACKED fp16 probabilities with v_dot2 (one VALU op per two keys, and the denominator is the sum of exactly
 // the values the PV MFMA multiplies).  ISA count per 64 keys x 32 queries at head_dim 80: 198 -> ~150 VALU issue slots.
-template <int DPAD, int DV16, int QB, bool CF = false>
+template <int DPAD, int DV16, int QB, bool CF = false, bool TP = false>
 __device__ __forceinline__ void attn_body(const AttnParams& p) {
     constexpr int KSTR = lds_stride_bytes(DPAD * 2) / 2;
     constexpr int DV = DV16 * 16;
@@ -121,6 +151,10 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     // length, row stride and buffers
     const int ntile_x = p.kx ? (p.Nkv_x + KT - 1) / KT : 0;
     const int T = nsrc_eff * ntile + ntile_x;
+    if (TP && T == 0) {                   // no key source in this phase (two-phase attention): block-uniform, before any barrier
+        attn_empty_phase<64 * QB>(p, bf, h, qblk, d);
+        return;
+    }
     int nx_s = 0, nx_t = 0;               // (source, tile-in-source) of the NEXT tile to load
     long nx_off = (long)__builtin_amdgcn_readfirstlane(p.src_idx[bf * p.nsrc]) * p.Nkv * p.ldkv;      // element offset of that source's first key row
     bool ld_tail = false;                 // the tile in the prefetch registers has rows past Nkv (zeroed at store time)
@@ -371,32 +405,47 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
             l += __shfl_xor(l, 16, 64);
             l += __shfl_xor(l, 32, 64);
         }
-        const float inv = 1.f / l;
+        float inv = 1.f / l, w1 = 0.f;
         const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * d;
+        if (TP && (p.state_out || p.state_in)) {          // two-phase attention: leave / merge the softmax state of this query (reference in log2 units)
+            const float m2 = CF ? mrun[qb] : mrun[qb] * c;
+            const long srow = (((long)bf * p.heads + h) * p.Nq + qrow) * 2;
+            if (p.state_in) {
+                const float2 st = *reinterpret_cast<const float2*>(p.state_in + srow);
+                attn_merge_coef(st.x, st.y, m2, l, w1, inv);
+            }
+            if (p.state_out && g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(m2, l);
+        }
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) {
             const int dc = dv * 16 + g * 4;
             if (dc < d) {
                 h4 ov;
+                if (TP && p.state_in) {
+                    const h4 o1 = *reinterpret_cast<const h4*>(op + dc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)fmaf((float)o1[r], w1, o[dv][qb][r] * inv);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                }
                 *reinterpret_cast<h4*>(op + dc) = ov;
             }
         }
     }
 }
 
-template <int DPAD, int DV16, int QB, bool CF = false>
+template <int DPAD, int DV16, int QB, bool CF = false, bool TP = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
-    attn_body<DPAD, DV16, QB, CF>(p);
+    attn_body<DPAD, DV16, QB, CF, TP>(p);
 }
 // same body, register budget capped for 3 waves per SIMD (the small-head-dim kernels are VALU/latency bound:
 // one more resident wave per SIMD hides the softmax behind another wave's MFMAs)
-template <int DPAD, int DV16, int QB, bool CF = false>
+template <int DPAD, int DV16, int QB, bool CF = false, bool TP = false>
 __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
-    attn_body<DPAD, DV16, QB, CF>(p);
+    attn_body<DPAD, DV16, QB, CF, TP>(p);
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -434,7 +483,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // front of the tile's barrier, a whole tile after the issue.  Rows past Nkv read a device zero page.
 __device__ __attribute__((aligned(256))) half_t uv_attn_zero_page[128];
 
-template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true, bool K16 = false>
+template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true, bool K16 = false, bool TP = false>
 __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     static_assert(!K16 || FOLD, "the 16-wide second k step carries the folded reference columns");
     constexpr int NW = 4;
@@ -463,6 +512,10 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     const int ntile = (p.Nkv + KT - 1) / KT;
     const int nsrc_eff = p.src_cnt ? p.src_cnt[bf] : p.nsrc;
     const int T = nsrc_eff * ntile;
+    if (TP && T == 0) {                   // no key source in this phase (two-phase attention): block-uniform, before any barrier
+        attn_empty_phase<64 * NW>(p, bf, h, qblk, D);
+        return;
+    }
     float lw_cur = p.src_logw ? p.src_logw[bf * p.nsrc] : 0.f;
 
     // ---- Q^T fragments (B operand): lane (q = l15, g) holds Q[q][ks*32 + g*8 .. +8]
@@ -973,17 +1026,32 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const float l = __shfl(o[DV16 - 1][qb][0], 32 + l15, 64);
-        const float inv = 1.f / l;
+        float inv = 1.f / l, w1 = 0.f;
         const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
+        if (TP && (p.state_out || p.state_in)) {          // two-phase attention (AttnParams): the reference in log2 units is M (FOLD) or the raw running max times c
+            const float m2 = FOLD ? mrun[qb] : mrun[qb] * c;
+            const long srow = (((long)bf * p.heads + h) * p.Nq + qrow) * 2;
+            if (p.state_in) {
+                const float2 st = *reinterpret_cast<const float2*>(p.state_in + srow);
+                attn_merge_coef(st.x, st.y, m2, l, w1, inv);
+            }
+            if (p.state_out && g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(m2, l);
+        }
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) {
             const int dc = dv * 16 + g * 4;
             if (dc < D) {
                 h4 ov;
+                if (TP && p.state_in) {
+                    const h4 o1 = *reinterpret_cast<const h4*>(op + dc);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)fmaf((float)o1[r], w1, o[dv][qb][r] * inv);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                }
                 *reinterpret_cast<h4*>(op + dc) = ov;
             }
         }
@@ -1556,8 +1624,46 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_occ2(AttnParams p) {
     attn_body<DPAD, DV16, QB>(p);
 }
 
+// two-phase launches (AttnParams::state_out / state_in): their own instantiations (TP), so the epilogue of the one-launch kernels is untouched —
+// the pipelined head_dim-40 kernel for long sequences with prescaled q, the generic body otherwise
+template <int DPAD, int DV16>
+int launch_attn_tp(const AttnParams& p, hipStream_t stream) {
+    if constexpr (DPAD == 64 && DV16 == 3) {
+        if (p.q_prescaled && p.Nq >= 2048) {
+            const int nqb4 = (p.Nq + 255) / 256;
+            hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    const int QB = p.Nq >= 512 ? 2 : 1;
+    const int nqb = (p.Nq + 64 * QB - 1) / (64 * QB);
+    dim3 grid(nqb * p.heads * p.BF), block(256);
+    if constexpr (DPAD >= 96) {
+        if (p.q_prescaled) {
+            if (QB == 2) {
+                if constexpr (DPAD == 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, true, true>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, true, true>), grid, block, 0, stream, p);
+            } else {
+                hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, true, true>), grid, block, 0, stream, p);
+            }
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    if (QB == 2) {
+        if constexpr (DPAD <= 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, false, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, false, true>), grid, block, 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, false, true>), grid, block, 0, stream, p);
+    }
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+
 template <int DPAD, int DV16>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
+    if (p.state_out || p.state_in) return launch_attn_tp<DPAD, DV16>(p, stream);
     static const int qb4 = getenv("UNIVST_ATTN_QB4") ? atoi(getenv("UNIVST_ATTN_QB4")) : 1;   // 64 query rows per wave for long sequences
     if constexpr (DPAD == 64 && DV16 == 3) {
         // UNIVST_ATTN_PP (A/B aid): 2 = software-pipelined kernel with scale/max folded into the MFMA when q is prescaled
@@ -1569,7 +1675,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
             // UNIVST_ATTN_STG (A/B aid): 1 (default) = K/V ring filled by LDS-DMA + one wave-wide reference test + 16-wide second k step;
             // 2 = the same with four per-block tests, 3 = with the 32-wide second k step; 0 = the round-2 kernel (ring through registers)
             static const int stg = getenv("UNIVST_ATTN_STG") ? atoi(getenv("UNIVST_ATTN_STG")) : 1;
-            if (pp == 2 && text) hipLaunchKernelGGL((attn_pp40_kernel<true, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            if (pp == 2 && text && !p.state_out && !p.state_in) hipLaunchKernelGGL((attn_pp40_kernel<true, 1>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2 && stg == 2) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, false, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2 && stg == 3) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, false>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             else if (pp == 2 && stg) hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
@@ -1585,7 +1691,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         static const int pp64 = getenv("UNIVST_ATTN_PP64") ? atoi(getenv("UNIVST_ATTN_PP64")) : 2;
         // (pp64 = 2, default since round 4: also the text queries of a joint attention — 333 rows over 12 621 keys — which otherwise take the
         // generic body: SD3.5 step 944 / 947 -> 934 / 943 ms, same box; 1 = image queries only)
-        if (pp64 && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && p.kx && p.Nq >= 192))) {
+        if (pp64 && !p.state_out && !p.state_in && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && p.kx && p.Nq >= 192))) {
             const int nqb4 = (p.Nq + 255) / 256;
             hipLaunchKernelGGL((attn_pp64_kernel<64, 4, 0>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
@@ -1600,7 +1706,7 @@ int launch_attn(const AttnParams& p, hipStream_t stream) {
         // (attn_body CF, built right after) takes 1.86 ms / 0.364 ms.  UNIVST_ATTN_PP80 = 1: grids of at most one round, 2: always (A/B aid)
         static const int pp80 = getenv("UNIVST_ATTN_PP80") ? atoi(getenv("UNIVST_ATTN_PP80")) : 0;
         const int nqb2 = (p.Nq + 127) / 128;
-        if (pp80 && p.q_prescaled && !p.kx && p.Nq >= 512 && (pp80 == 2 || (long)nqb2 * p.heads * p.BF <= 512)) {
+        if (pp80 && !p.state_out && !p.state_in && p.q_prescaled && !p.kx && p.Nq >= 512 && (pp80 == 2 || (long)nqb2 * p.heads * p.BF <= 512)) {
             hipLaunchKernelGGL((attn_pp64_kernel<80, 2, 0>), dim3(nqb2 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
             return UV_OK;
@@ -1690,7 +1796,7 @@ int uv_launch_attention(const AttnParams& p0, hipStream_t stream) {
 static int attn_dispatch(const AttnParams& p, hipStream_t stream) {
     // text cross-attention: one short source, K/V held in registers (attn_text_kernel).  UNIVST_ATTN_TEXT=0: generic kernels (A/B aid)
     static const int text_env = getenv("UNIVST_ATTN_TEXT") ? atoi(getenv("UNIVST_ATTN_TEXT")) : 1;
-    if (text_env && !p.kx && p.nsrc == 1 && p.Nkv <= 80 && !p.src_logw && (p.d == 40 || p.d == 80) && p.Nq >= 256) {
+    if (text_env && !p.kx && !p.state_out && !p.state_in && p.nsrc == 1 && p.Nkv <= 80 && !p.src_logw && (p.d == 40 || p.d == 80) && p.Nq >= 256) {
         const int nchunk = (p.Nq + 1023) / 1024;
         const dim3 grid((unsigned)(nchunk * p.heads * p.BF));
         if (p.d == 40) hipLaunchKernelGGL((attn_text_kernel<40>), grid, dim3(256), 0, stream, p);

@@ -92,6 +92,14 @@ struct AttnParams {
     const int* x_idx = nullptr;     // [BF] row block of the extra segment for every query frame
     long ldkv_x = 0;
     int Nkv_x = 0;
+    // TWO-PHASE attention (round 6; the frame shard consumes its LOCAL key frames while the halo frames are still on the wire): online softmax is
+    // order independent, so the key set of a query may be split over two launches.  Phase 1 (state_out set) writes its normalised rows to o as usual
+    // and leaves per (frame, head, query) the pair (m, l) = (reference of the exponentials in log2 units, denominator w.r.t. it) in
+    // state_out[((bf * heads + h) * Nq + i) * 2]; a frame with src_cnt == 0 gets zero rows and l = 0.  Phase 2 (state_in set) runs over the remaining
+    // sources and MERGES: o <- (o1 * l1 * 2^(m1 - m) + acc2 * 2^(m2 - m)) / (l1 * 2^(m1 - m) + l2 * 2^(m2 - m)), m = max(m1, m2) — exact up to the fp16
+    // rounding of o1; frames with src_cnt == 0 keep their phase-1 rows.  Served by attn_body and attn_pp40_kernel (the dispatcher keeps such launches there).
+    float* state_out = nullptr;
+    const float* state_in = nullptr;
 };
 
 // The text cross-attention of a transformer block as ONE launch (fused.hip: attention.py:321-327 = norm2 -> attn2 -> + residual)
