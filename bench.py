@@ -525,7 +525,7 @@ def main():
         er, ew = (int(v) for v in a.emulate_rank.split("/"))
         emu = (er, ew)
         wire = [float(v) for v in a.emulate_wire.split(",")] if a.emulate_wire else None
-        shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew, *(wire or [])))
+        shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew, *(wire or []), kv_in_library=True))
     else:
         shard = FrameShard(rank, world, F_total)
     unet = synth.build_unet(config=synth.SD21_UNET_CONFIG if a.model == "sd21" else None, device=dev, seed=33)
@@ -543,6 +543,12 @@ def main():
         mask_m = _native.mask_resize(mask.reshape(-1, 8 * h, 8 * h).contiguous(), h, h)
         mask_m = mask_m.reshape(-1, h, h)[shard.f0:shard.f0 + shard.local].contiguous()
     shard.attach(unet, max_tokens=h * h)
+    if emu is not None and a.emulate_wire:
+        # the K/V exchanges' wire time is modelled INSIDE the library, on the forked stream the real multicast runs on (csrc/unet.hip Fwd::kv_post), so the
+        # emulation shows what the overlap hides; the GroupNorm all-reduces' flag round trips stay in NullComm on the forward's stream
+        unet.set_native_option("emu_wire_gbps", int(wire[0]))
+        if len(wire) > 1:
+            unet.set_native_option("emu_wire_lat_us", int(wire[1]))
     shard_check = None
     if world > 1 and not a.no_shard_check:
         # First contact with real multi-GPU hardware happens in the driver's run: before anything is timed, every rank compares ONE
@@ -586,12 +592,14 @@ def main():
     sync()
     if emu is not None:
         shard.comm.wire_us = 0.0
+        _native.unet_query(unet._native_handle, "emu_wire_us")
     t0 = time.perf_counter()
     for i in idx:
         lat = step(i, lat)
     sync()
     dt = time.perf_counter() - t0
-    wire_ms_per_step = (shard.comm.wire_us / a.steps / 1e3) if emu is not None and a.emulate_wire else None
+    wire_ms_per_step = ((shard.comm.wire_us + _native.unet_query(unet._native_handle, "emu_wire_us")) / a.steps / 1e3) if emu is not None and a.emulate_wire else None
+    kv_overlap = os.environ.get("UNIVST_KV_OVERLAP", "1") != "0"
     if dist is not None:
         tmax = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -610,7 +618,7 @@ def main():
                                 f"{a.model}_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "schedule_steps": "all 50" if a.steps == 50 else (f"{a.steps} of 50, evenly spread" if a.steps < 50 else f"{a.steps} (wrapping modulo 50)"),
-                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} ({'wire modelled at ' + a.emulate_wire + ' GB/s per link, serial' if a.emulate_wire else 'no wire'})" if emu else "single") if world == 1 else f"frames{world}",
+                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} ({'wire modelled at ' + a.emulate_wire + ' GB/s per link, ' + ('K/V exchange on the forked stream' if kv_overlap else 'serial') if a.emulate_wire else 'no wire'})" if emu else "single") if world == 1 else f"frames{world}",
                    "comm": None if world == 1 else type(shard.comm).__name__, "shard_check": shard_check,
                    **({"modelled_wire_ms_per_step": round(wire_ms_per_step, 3)} if wire_ms_per_step is not None else {}),
                    "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else

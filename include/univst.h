@@ -30,7 +30,7 @@ const char* univst_last_error(void);
 /* Bumped whenever an existing entry changes its signature or meaning (2: univst_sd3_joint_attention takes (shift, beta) instead of the
  * window parameters, round 4).  A binding checks it at load time (univst_amd/_native.py does): a caller built against an older header would
  * otherwise pass silently misinterpreted arguments. */
-#define UNIVST_ABI_VERSION 2
+#define UNIVST_ABI_VERSION 3
 int univst_abi_version(void);
 
 /* ------------------------------------------------------------------ UNet handle
@@ -127,10 +127,18 @@ int univst_unet_set_comm_native(univst_unet* h, univst_comm* comm);
  *             experiment kept as a switch: -13 % on the isolated chain (tools/bench_mall_bands.py), +0.4 ms per step in the graph.
  *   "gn_fold" (default 1, env UNIVST_GN_FOLD): the per-frame GroupNorm in front of a transformer block (attention.py:121) is folded into proj_in as per-frame
  *             weight sets + an fp32 bias where the copies are cheap against the apply pass they replace (the 64x64 level); 0: always the apply pass.
- *   "attn2_fused" (default 1, env UNIVST_ATTN2_FUSED=0 disables it library-wide): the text cross-attention of a transformer block (attention.py:321-327)
+ *   "attn2_fused" (default 2, env UNIVST_ATTN2_FUSED=0 disables it library-wide): the text cross-attention of a transformer block (attention.py:321-327)
  *             as one launch (univst_attn2_fused) where the level's shape is served, instead of q projection + attention + out projection; 2 (default): with the
- *             self-attention's out projection + residual in front of it (univst_attn12_fused), 1: attn2 alone, 0: off. */
+ *             self-attention's out projection + residual in front of it (univst_attn12_fused), 1: attn2 alone, 0: off.
+ *   "kv_overlap" (default 1, env UNIVST_KV_OVERLAP; round 6): the frame shard's K/V exchange of a transformer block (attention.py:384-413 across GPUs)
+ *             is issued on a forked stream as soon as proj_in has written the boundary frames' hidden rows and joined in front of the halo phase of
+ *             the two-phase attention; 0: issued on the forward's own stream (serial; A/B aid).  Results are identical.
+ *   "emu_wire_gbps" / "emu_wire_lat_us" (default 0 = off / 3; bench.py --emulate-wire): with a callback communicator that moves nothing, every
+ *             exchange occupies the forked stream for latency + (packs on this rank's busiest link) x pack bytes / rate — a 1-GPU box's stand-in for
+ *             the xGMI transfer; the accumulated time is univst_unet_query("emu_wire_us"). */
 int univst_unet_set_option(univst_unet* h, const char* name, int value);
+/* read-outs of a handle: "emu_wire_us" (modelled wire time issued since the last query; reading resets it), "arena_high_water" (bytes). */
+int univst_unet_query(univst_unet* h, const char* name, double* out);
 
 /* ------------------------------------------------------------------ temporal VAE handle
  * The VAE behind the pipeline's decode / encode call sites (stable_diffusion.py:369-394 decode_latents, :793-818 get_images_from_latents,

@@ -39,7 +39,7 @@ def test_exports_match_header(lib):
 def test_version_and_error_string(lib):
     from univst_amd import _native
     src = open(os.path.join(ROOT, "include", "univst.h")).read()
-    assert lib.univst_abi_version() == _native.ABI_VERSION == int(re.search(r"#define UNIVST_ABI_VERSION (\d+)", src).group(1)) == 2
+    assert lib.univst_abi_version() == _native.ABI_VERSION == int(re.search(r"#define UNIVST_ABI_VERSION (\d+)", src).group(1)) == 3
     assert isinstance(lib.univst_last_error(), bytes)
 
 

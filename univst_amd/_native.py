@@ -59,6 +59,7 @@ SIGNATURES = {
     "univst_unet_forward": (_I, [_P, _P, _F, _P, _I, _I, _I, _I, _I, C.POINTER(PnP), _P, _P, _I, _P]),
     "univst_unet_set_comm": (_I, [_P, _I, _I, _P, _L, ALLREDUCE_FN, KVEXCHANGE_FN, _P]),
     "univst_unet_set_option": (_I, [_P, C.c_char_p, _I]),
+    "univst_unet_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     "univst_comm_create": (_I, [_I, _I, _L, C.POINTER(_P)]),
     "univst_comm_handle_bytes": (_I, []),
     "univst_comm_export": (_I, [_P, _P]),
@@ -126,7 +127,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 2      # include/univst.h UNIVST_ABI_VERSION
+ABI_VERSION = 3      # include/univst.h UNIVST_ABI_VERSION
 
 
 def lib_path() -> str:
@@ -594,6 +595,13 @@ def debug_tr16():
     out = torch.empty(256, device="cuda", dtype=torch.float32)
     check(load().univst_debug_tr16(ptr(out), stream_ptr()), "debug_tr16")
     return out
+
+
+def unet_query(handle, name: str) -> float:
+    """read-out of a UNet handle (include/univst.h ``univst_unet_query``): "emu_wire_us", "arena_high_water"."""
+    out = C.c_double(0.0)
+    check(load().univst_unet_query(handle, name.encode(), C.byref(out)), f"unet_query({name})")
+    return out.value
 
 
 def delay_us(us: float):

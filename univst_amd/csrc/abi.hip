@@ -60,6 +60,7 @@ int univst_unet_create(const univst_unet_cfg* cfg, univst_unet** out) {
     if (const char* e = getenv("UNIVST_GN_FOLD")) h->impl.gn_fold = atoi(e) != 0;
     if (const char* e = getenv("UNIVST_ATTN2_PRE")) h->impl.attn2_fused = atoi(e) ? 2 : 1;
     if (const char* e = getenv("UNIVST_CHAIN_BANDS")) h->impl.chain_bands = atoi(e) < 0 ? 0 : atoi(e);
+    if (const char* e = getenv("UNIVST_KV_OVERLAP")) h->impl.kv_overlap = atoi(e) != 0;
     *out = h;
     return UV_OK;
 }
@@ -88,7 +89,35 @@ int univst_unet_set_option(univst_unet* h, const char* name, int value) {
         h->impl.chain_bands = value;
         return UV_OK;
     }
+    if (!strcmp(name, "kv_overlap")) {
+        h->impl.kv_overlap = value != 0;
+        return UV_OK;
+    }
+    if (!strcmp(name, "emu_wire_gbps")) {
+        UV_REQUIRE(value >= 0 && value <= 10000, "unet_set_option: emu_wire_gbps is a per-link rate in GB/s (0: off)");
+        h->impl.emu_wire_gbps = value;
+        return UV_OK;
+    }
+    if (!strcmp(name, "emu_wire_lat_us")) {
+        UV_REQUIRE(value >= 0 && value <= 100000, "unet_set_option: emu_wire_lat_us is a latency in microseconds");
+        h->impl.emu_wire_lat_us = value;
+        return UV_OK;
+    }
     uv_set_error("unet_set_option: unknown option '%s'", name);
+    return UV_ERR_ARG;
+}
+int univst_unet_query(univst_unet* h, const char* name, double* out) {
+    UV_REQUIRE(h && name && out, "unet_query: null argument");
+    if (!strcmp(name, "emu_wire_us")) {          // modelled wire time issued since the last query (reading resets it)
+        *out = h->impl.emu_wire_us;
+        h->impl.emu_wire_us = 0.0;
+        return UV_OK;
+    }
+    if (!strcmp(name, "arena_high_water")) {
+        *out = (double)h->impl.arena.high_water;
+        return UV_OK;
+    }
+    uv_set_error("unet_query: unknown quantity '%s'", name);
     return UV_ERR_ARG;
 }
 int univst_unet_destroy(univst_unet* h) {

@@ -50,7 +50,7 @@ __device__ __forceinline__ void attn_merge_coef(float m1, float l1, float m2, fl
 // whose two sources are both remote): phase 1 leaves zero rows with l = 0, phase 2 keeps what phase 1 wrote.  Block-uniform.
 template <int RB>
 __device__ __forceinline__ void attn_empty_phase(const AttnParams& p, int bf, int h, int qblk, int d) {
-    if (p.state_in || !p.state_out) return;
+    if (!p.state_out) return;
     const int tid = threadIdx.x;
     const int dch = d / 4;
     for (int i = tid; i < RB * dch; i += 256) {
@@ -67,7 +67,7 @@ __device__ __forceinline__ void attn_empty_phase(const AttnParams& p, int bf, in
 // (cf[qb] = lw - mrun, what attn_pp64_kernel calls cfold), so the per-score scale fma disappears; the rare reference change shifts the pending scores.
 // Without ONES the row sums are taken from the PACKED fp16 probabilities with v_dot2 (one VALU op per two keys, and the denominator is the sum of exactly
 // the values the PV MFMA multiplies).  ISA count per 64 keys x 32 queries at head_dim 80: 198 -> ~150 VALU issue slots.
-template <int DPAD, int DV16, int QB, bool CF = false, bool TP = false>
+template <int DPAD, int DV16, int QB, bool CF = false, int TP = 0>
 __device__ __forceinline__ void attn_body(const AttnParams& p) {
     constexpr int KSTR = lds_stride_bytes(DPAD * 2) / 2;
     constexpr int DV = DV16 * 16;
@@ -409,21 +409,25 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
         const int qrow = qblk * 64 * QB + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * d;
-        if (TP && (p.state_out || p.state_in)) {          // two-phase attention: leave / merge the softmax state of this query (reference in log2 units)
+        // two-phase attention: TP == 1 leaves the softmax state of this query (reference in log2 units, denominator), TP == 2 merges phase 1's rows with
+        // this launch's accumulator.  Two instantiations on purpose: the first phase is the one-launch epilogue plus one store, and the merge weights exist
+        // only where they are used (as one kernel with run-time branches the QB = 2 bodies at head_dim 40 / 80 produced sporadic x * w1 = +-0 elements).
+        if constexpr (TP != 0) {
             const float m2 = CF ? mrun[qb] : mrun[qb] * c;
             const long srow = (((long)bf * p.heads + h) * p.Nq + qrow) * 2;
-            if (p.state_in) {
+            if constexpr (TP == 1) {
+                if (g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(m2, l);
+            } else {
                 const float2 st = *reinterpret_cast<const float2*>(p.state_in + srow);
                 attn_merge_coef(st.x, st.y, m2, l, w1, inv);
             }
-            if (p.state_out && g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(m2, l);
         }
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) {
             const int dc = dv * 16 + g * 4;
             if (dc < d) {
                 h4 ov;
-                if (TP && p.state_in) {
+                if constexpr (TP == 2) {
                     const h4 o1 = *reinterpret_cast<const h4*>(op + dc);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ov[r] = (half_t)fmaf((float)o1[r], w1, o[dv][qb][r] * inv);
@@ -437,13 +441,13 @@ __device__ __forceinline__ void attn_body(const AttnParams& p) {
     }
 }
 
-template <int DPAD, int DV16, int QB, bool CF = false, bool TP = false>
+template <int DPAD, int DV16, int QB, bool CF = false, int TP = 0>
 __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     attn_body<DPAD, DV16, QB, CF, TP>(p);
 }
 // same body, register budget capped for 3 waves per SIMD (the small-head-dim kernels are VALU/latency bound:
 // one more resident wave per SIMD hides the softmax behind another wave's MFMAs)
-template <int DPAD, int DV16, int QB, bool CF = false, bool TP = false>
+template <int DPAD, int DV16, int QB, bool CF = false, int TP = 0>
 __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
     attn_body<DPAD, DV16, QB, CF, TP>(p);
 }
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256, 3) void attn_kernel_occ3(AttnParams p) {
 // front of the tile's barrier, a whole tile after the issue.  Rows past Nkv read a device zero page.
 __device__ __attribute__((aligned(256))) half_t uv_attn_zero_page[128];
 
-template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true, bool K16 = false, bool TP = false>
+template <bool FOLD, int TAG = 0, int STG = 0, bool ONEB = true, bool K16 = false, int TP = 0>
 __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
     static_assert(!K16 || FOLD, "the 16-wide second k step carries the folded reference columns");
     constexpr int NW = 4;
@@ -1030,21 +1034,22 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
         const int qrow = qblk * 64 * NW + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
-        if (TP && (p.state_out || p.state_in)) {          // two-phase attention (AttnParams): the reference in log2 units is M (FOLD) or the raw running max times c
+        if constexpr (TP != 0) {          // two-phase attention (AttnParams; TP == 1 first phase, 2 merge phase): the reference in log2 units is M (FOLD) or the raw running max times c
             const float m2 = FOLD ? mrun[qb] : mrun[qb] * c;
             const long srow = (((long)bf * p.heads + h) * p.Nq + qrow) * 2;
-            if (p.state_in) {
+            if constexpr (TP == 1) {
+                if (g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(m2, l);
+            } else {
                 const float2 st = *reinterpret_cast<const float2*>(p.state_in + srow);
                 attn_merge_coef(st.x, st.y, m2, l, w1, inv);
             }
-            if (p.state_out && g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(m2, l);
         }
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) {
             const int dc = dv * 16 + g * 4;
             if (dc < D) {
                 h4 ov;
-                if (TP && p.state_in) {
+                if constexpr (TP == 2) {
                     const h4 o1 = *reinterpret_cast<const h4*>(op + dc);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) ov[r] = (half_t)fmaf((float)o1[r], w1, o[dv][qb][r] * inv);
@@ -1626,12 +1631,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel_occ2(AttnParams p) {
 
 // two-phase launches (AttnParams::state_out / state_in): their own instantiations (TP), so the epilogue of the one-launch kernels is untouched —
 // the pipelined head_dim-40 kernel for long sequences with prescaled q, the generic body otherwise
-template <int DPAD, int DV16>
+template <int DPAD, int DV16, int TP>
 int launch_attn_tp(const AttnParams& p, hipStream_t stream) {
     if constexpr (DPAD == 64 && DV16 == 3) {
         if (p.q_prescaled && p.Nq >= 2048) {
             const int nqb4 = (p.Nq + 255) / 256;
-            hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true, true>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true, TP>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
             return UV_OK;
         }
@@ -1642,20 +1647,20 @@ int launch_attn_tp(const AttnParams& p, hipStream_t stream) {
     if constexpr (DPAD >= 96) {
         if (p.q_prescaled) {
             if (QB == 2) {
-                if constexpr (DPAD == 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, true, true>), grid, block, 0, stream, p);
-                else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, true, true>), grid, block, 0, stream, p);
+                if constexpr (DPAD == 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, true, TP>), grid, block, 0, stream, p);
+                else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, true, TP>), grid, block, 0, stream, p);
             } else {
-                hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, true, true>), grid, block, 0, stream, p);
+                hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, true, TP>), grid, block, 0, stream, p);
             }
             UV_LAUNCH_CHECK();
             return UV_OK;
         }
     }
     if (QB == 2) {
-        if constexpr (DPAD <= 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, false, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, false, true>), grid, block, 0, stream, p);
+        if constexpr (DPAD <= 96) hipLaunchKernelGGL((attn_kernel_occ3<DPAD, DV16, 2, false, TP>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 2, false, TP>), grid, block, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, false, true>), grid, block, 0, stream, p);
+        hipLaunchKernelGGL((attn_kernel<DPAD, DV16, 1, false, TP>), grid, block, 0, stream, p);
     }
     UV_LAUNCH_CHECK();
     return UV_OK;
@@ -1663,7 +1668,8 @@ int launch_attn_tp(const AttnParams& p, hipStream_t stream) {
 
 template <int DPAD, int DV16>
 int launch_attn(const AttnParams& p, hipStream_t stream) {
-    if (p.state_out || p.state_in) return launch_attn_tp<DPAD, DV16>(p, stream);
+    if (p.state_out) return launch_attn_tp<DPAD, DV16, 1>(p, stream);
+    if (p.state_in) return launch_attn_tp<DPAD, DV16, 2>(p, stream);
     static const int qb4 = getenv("UNIVST_ATTN_QB4") ? atoi(getenv("UNIVST_ATTN_QB4")) : 1;   // 64 query rows per wave for long sequences
     if constexpr (DPAD == 64 && DV16 == 3) {
         // UNIVST_ATTN_PP (A/B aid): 2 = software-pipelined kernel with scale/max folded into the MFMA when q is prescaled
@@ -1783,6 +1789,7 @@ int uv_launch_attention(const AttnParams& p0, hipStream_t stream) {
     UV_REQUIRE(p.nsrc >= 1 && p.Nkv >= 1 && p.Nq >= 1, "attention: empty problem");
     UV_REQUIRE(p.ldq % 8 == 0 && p.ldkv % 8 == 0 && p.ldo % 4 == 0, "attention: row strides must be multiples of 8");
     UV_REQUIRE(!p.kx || (p.vx && p.x_idx && p.Nkv_x >= 1 && p.ldkv_x % 8 == 0), "attention: extra key segment needs vx, x_idx, Nkv_x >= 1 and a row stride that is a multiple of 8");
+    UV_REQUIRE(!(p.state_out && p.state_in), "attention: a launch is the first phase (state_out) or the merge phase (state_in) of a two-phase attention, not both");
     const double nkv = (double)p.nsrc * p.Nkv;
     const int cls = (p.nsrc == 1 && p.Nkv <= 128) ? UV_CLS_ATTN_TEXT
                     : (p.d == 40 && p.Nq >= 2048) ? UV_CLS_ATTN_D40 : (p.d == 80 ? UV_CLS_ATTN_D80 : UV_CLS_ATTN_OTHER);

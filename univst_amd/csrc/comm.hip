@@ -152,14 +152,14 @@ static int comm_allreduce_cb(void* user, int64_t byte_off, int count) {
     univst_comm* c = (univst_comm*)user;
     return uv_comm_allreduce(c, reinterpret_cast<float*>(c->mine + UV_OFF_WS + byte_off), count, c->stream);
 }
-static int comm_kv_cb(void* user, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes) {
-    univst_comm* c = (univst_comm*)user;
+// (round 6: `s` is the stream the whole exchange is issued on — the UNet graph's FORKED stream, so that the multicast and the wait for the
+// peers' packs run beside the rank's own q|k|v projection and the local phase of its attention; unet.hip::Fwd::kv_post)
+static int comm_kv_issue(univst_comm* c, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes, hipStream_t s) {
     int rc = comm_check(c);
     if (rc) return rc;
     UV_REQUIRE(nbytes % 16 == 0, "kv_exchange: pack size must be a multiple of 16 bytes");
     const unsigned epoch = ++c->kv_epoch;
     const int par = epoch & 1;
-    hipStream_t s = c->stream;
     auto flag = [&](int r, int which) { return reinterpret_cast<unsigned*>(c->peer[r] + UV_OFF_FLAGS) + 32 + par * 2 + which; };
     const long nvec = nbytes / 16;
     const unsigned grid = (unsigned)((nvec + 256 * 8 - 1) / (256 * 8) < 1024 ? (nvec + 256 * 8 - 1) / (256 * 8) : 1024);
@@ -185,6 +185,11 @@ static int comm_kv_cb(void* user, int64_t o_send, int64_t o_first, int64_t o_pre
     if (c->rank > 0) hipLaunchKernelGGL(comm_wait_kernel, dim3(1), dim3(2), 0, s, flag(c->rank, 0), flag(c->rank, 1), epoch, c->status);
     UV_LAUNCH_CHECK();
     return UV_OK;
+}
+
+static int comm_kv_cb(void* user, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes) {
+    univst_comm* c = (univst_comm*)user;
+    return comm_kv_issue(c, o_send, o_first, o_prev, o_rfirst, nbytes, c->stream);
 }
 
 extern "C" {
@@ -292,6 +297,11 @@ int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, 
                "kv_exchange: a %ld-byte pack does not fit the communicator's %ld-byte workspace", nbytes, c->ws_bytes);
     c->stream = s;
     return comm_kv_cb(c, o_send, o_first, o_prev, o_rfirst, nbytes);
+}
+// the UNet graph's exchange: same packs, issued on `s` (its forked stream) without re-binding the stream of the all-reduces
+int uv_comm_kv_exchange_on(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s) {
+    UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
+    return comm_kv_issue(c, o_send, o_first, o_prev, o_rfirst, nbytes, s);
 }
 int uv_comm_barrier(univst_comm* c, hipStream_t s) {             // (the first 64 KiB of the workspace are the all-reduce scratch of both paths)
     return uv_comm_allreduce(c, reinterpret_cast<float*>(c->mine + UV_OFF_WS), 1, s);

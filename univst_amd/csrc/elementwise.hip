@@ -87,25 +87,18 @@ __global__ void add_bias_rows_kernel(half_t* __restrict__ x, const half_t* __res
     if (i < rows * C) x[i] = (half_t)((float)x[i] + (float)b[i % C]);
 }
 
-// K|V columns [C,3C) of frame `frame` of every branch -> packed [B, N, 2C]  (frame-shard halo / broadcast payload)
-__global__ void kv_pack_kernel(const half_t* __restrict__ qkv, long ld, int C, int N, int B, int fpb, int frame, half_t* __restrict__ dst) {
-    const int ch = 2 * C / 8;
+// `width` columns from column `col0` of frame `frame` of every branch -> packed [B, N, width]: the frame-shard halo / broadcast payload.
+// Round 6: the payload is the transformer block's HIDDEN rows (col0 = 0, width = C; the receiver projects them to K | V itself — half the
+// bytes of the K|V pack, and they exist before the q|k|v GEMM runs)
+__global__ void rows_pack_kernel(const half_t* __restrict__ src, long ld, int col0, int width, int N, int B, int fpb, int frame, half_t* __restrict__ dst) {
+    const int ch = width / 8;
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * N * ch) return;
     int c8 = (int)(i % ch);
     long r = i / ch;
     int n = (int)(r % N), b = (int)(r / N);
-    const half_t* src = qkv + ((long)(b * fpb + frame) * N + n) * ld + C + c8 * 8;
-    *reinterpret_cast<h8*>(dst + r * 2 * C + c8 * 8) = *reinterpret_cast<const h8*>(src);
-}
-// packed [B, N, 2C] -> K|V columns of rows [row0 + b*N, ...) of the QKV buffer (the extra frames appended to it)
-__global__ void kv_unpack_kernel(const half_t* __restrict__ src, half_t* __restrict__ qkv, long ld, int C, int N, int B, long row0) {
-    const int ch = 2 * C / 8;
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * N * ch) return;
-    int c8 = (int)(i % ch);
-    long r = i / ch;
-    *reinterpret_cast<h8*>(qkv + (row0 + r) * ld + C + c8 * 8) = *reinterpret_cast<const h8*>(src + r * 2 * C + c8 * 8);
+    const half_t* from = src + ((long)(b * fpb + frame) * N + n) * ld + col0 + c8 * 8;
+    *reinterpret_cast<h8*>(dst + r * width + c8 * 8) = *reinterpret_cast<const h8*>(from);
 }
 
 }  // namespace
@@ -148,13 +141,9 @@ int uv_launch_add_bias_rows(half_t* x, const half_t* b, long rows, int C, hipStr
     return UV_OK;
 }
 
-int uv_launch_kv_pack(const half_t* qkv, long ld, int C, int N, int B, int fpb, int frame, half_t* dst, hipStream_t s) {
-    hipLaunchKernelGGL(kv_pack_kernel, dim3(nblk((long)B * N * (2 * C / 8), 256)), dim3(256), 0, s, qkv, ld, C, N, B, fpb, frame, dst);
-    UV_LAUNCH_CHECK();
-    return UV_OK;
-}
-int uv_launch_kv_unpack(const half_t* src, half_t* qkv, long ld, int C, int N, int B, long row0, hipStream_t s) {
-    hipLaunchKernelGGL(kv_unpack_kernel, dim3(nblk((long)B * N * (2 * C / 8), 256)), dim3(256), 0, s, src, qkv, ld, C, N, B, row0);
+int uv_launch_rows_pack(const half_t* src, long ld, int col0, int width, int N, int B, int fpb, int frame, half_t* dst, hipStream_t s) {
+    UV_REQUIRE(width % 8 == 0 && col0 % 8 == 0 && ld % 8 == 0, "rows_pack: columns must come in groups of 8");
+    hipLaunchKernelGGL(rows_pack_kernel, dim3(nblk((long)B * N * (width / 8), 256)), dim3(256), 0, s, src, ld, col0, width, N, B, fpb, frame, dst);
     UV_LAUNCH_CHECK();
     return UV_OK;
 }

@@ -186,8 +186,7 @@ int uv_launch_latent_adain(const half_t* cnt, const half_t* sty, half_t* out, in
 int uv_launch_latent_adain_stats(const half_t* cnt, float* st, int Cl, int F, int HW, hipStream_t stream);
 int uv_launch_latent_adain_apply(const half_t* cnt, const half_t* sty, const float* st, long n_total, half_t* out, int Cl, int F, int HW,
                                  hipStream_t stream);
-int uv_launch_kv_pack(const half_t* qkv, long ld, int C, int N, int B, int frames_per_branch, int frame, half_t* dst, hipStream_t s);
-int uv_launch_kv_unpack(const half_t* src, half_t* qkv, long ld, int C, int N, int B, long row0, hipStream_t s);
+int uv_launch_rows_pack(const half_t* src, long ld, int col0, int width, int N, int B, int frames_per_branch, int frame, half_t* dst, hipStream_t s);
 int uv_launch_ncfhw_to_nhwc(const half_t* x, half_t* y, int B, int Cl, int F, int HW, int CP, hipStream_t s);
 int uv_launch_nhwc_to_ncfhw(const half_t* x, int ldx, half_t* y, int B, int Cl, int F, int HW, hipStream_t s);
 int uv_launch_timestep_embed(float t, half_t* out, int B, int dim, int flip, float shift, hipStream_t s);

@@ -16,6 +16,7 @@ unsigned uv_comm_kv_parity(const univst_comm* c);
 int uv_comm_poll(univst_comm* c);
 int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s);
 int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
+int uv_comm_kv_exchange_on(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
 int uv_comm_barrier(univst_comm* c, hipStream_t s);
 char* uv_comm_ws(univst_comm* c);
 long uv_comm_ws_bytes(const univst_comm* c);
@@ -74,6 +75,15 @@ struct UNet {
     char* comm_ws = nullptr;
     long comm_ws_bytes = 0;
     struct univst_comm* native_comm = nullptr;   // set when the hooks above are the library's own IPC communicator (comm.hip)
+    // round 6: the K/V exchange of a transformer block runs on a FORKED stream beside the block's own q|k|v projection and the local phase of its
+    // attention (Fwd::kv_post / kv_join); kv_overlap = 0 issues it on the forward's stream instead (A/B aid).  emu_wire_*: bench.py --emulate-wire —
+    // with a communicator that moves nothing (NullComm) a delay kernel on the forked stream stands in for the slowest transfer of each exchange.
+    int kv_overlap = 1;
+    int emu_wire_gbps = 0, emu_wire_lat_us = 3;
+    double emu_wire_us = 0.0;                    // modelled wire time issued since the last univst_unet_query("emu_wire_us")
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int comm_streams();                          // creates the forked stream + events on first use
 
     ~UNet();
     int load_tensor(const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, hipStream_t s);

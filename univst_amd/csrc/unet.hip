@@ -258,6 +258,19 @@ UNet::~UNet() {
     for (auto& kv : idx_tables) (void)hipFree(kv.second);
     if (arena.base) (void)hipFree(arena.base);
     if (d_counter) (void)hipFree(d_counter);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (xstream) (void)hipStreamDestroy(xstream);
+}
+
+int UNet::comm_streams() {
+    if (xstream) return UV_OK;
+    int lo = 0, hi = 0;                         // (numerically lowest = greatest priority): the exchange's few kernels go ahead of the queued compute
+    UV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    UV_HIP(hipStreamCreateWithPriority(&xstream, hipStreamNonBlocking, hi));
+    UV_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    UV_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    return UV_OK;
 }
 
 int UNet::load_tensor(const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, hipStream_t s) {
@@ -608,19 +621,44 @@ int UNet::reserve(int B, int F, int H, int Wd) {
                 lw.push_back(j < (int)uniq.size() ? log2f((float)mult[j]) : 0.f);
             }
         };
+        // Round 6, ranks > 0 of a frame shard: the key set of every query is split into the frames this rank HOLDS (phase 1, runs while the halo frames
+        // are on the wire) and the two halo frames (phase 2, continues from phase 1's softmax state): the primary tables carry the local sources — a
+        // frame may have none: PnP at f = 0 — and a second block [idx stock 3BF | idx pnp 2BF | cnt stock BF | cnt pnp BF] behind them the halo ones
+        // (never duplicates: prev and first are different row blocks even where they are the same global frame).
+        auto emit_split = [&](std::vector<int> local, std::vector<int> halo, int width, std::vector<int>& t2, std::vector<int>& cnt2, int self) {
+            cnt.push_back((int)local.size());
+            for (int j = 0; j < width; ++j) {
+                t.push_back(j < (int)local.size() ? local[j] : self);
+                lw.push_back(0.f);
+            }
+            cnt2.push_back((int)halo.size());
+            for (int j = 0; j < width; ++j) t2.push_back(j < (int)halo.size() ? halo[j] : self);
+        };
+        std::vector<int> t2s, t2p, c2s, c2p;
         for (int b = 0; b < B; ++b)
-            for (int f = 0; f < F; ++f) emit({prev(b, f), b * F + f, first(b)}, 3);   // stock: [-1, 0, 'first'] (attention.py:356)
+            for (int f = 0; f < F; ++f) {                                             // stock: [-1, 0, 'first'] (attention.py:356)
+                if (!ext) emit({prev(b, f), b * F + f, first(b)}, 3);
+                else if (f == 0) emit_split({b * F + f}, {prev(b, f), first(b)}, 3, t2s, c2s, b * F + f);
+                else emit_split({prev(b, f), b * F + f}, {first(b)}, 3, t2s, c2s, b * F + f);
+            }
         for (int b = 0; b < B; ++b)
-            for (int f = 0; f < F; ++f) emit({prev(b, f), first(b)}, 2);              // PnP: [-1, 'first'] (pnp_utils.py:25)
+            for (int f = 0; f < F; ++f) {                                             // PnP: [-1, 'first'] (pnp_utils.py:25)
+                if (!ext) emit({prev(b, f), first(b)}, 2);
+                else if (f == 0) emit_split({}, {prev(b, f), first(b)}, 2, t2p, c2p, b * F + f);
+                else emit_split({prev(b, f)}, {first(b)}, 2, t2p, c2p, b * F + f);
+            }
         for (int b = 0; b < B; ++b)
             for (int f = 0; f < F; ++f) t.push_back(b);   // text: one [77, C] block per branch
         // layout of the device table: [idx stock 3BF | idx pnp 2BF | idx text BF | cnt stock BF | cnt pnp BF | logw stock 3BF | logw pnp 2BF]
+        // (+ on ranks > 0 of a shard: [idx stock2 3BF | idx pnp2 2BF | cnt stock2 BF | cnt pnp2 BF])
         for (int v : cnt) t.push_back(v);
         for (float v : lw) {
             int bits;
             memcpy(&bits, &v, 4);
             t.push_back(bits);
         }
+        for (auto* v : {&t2s, &t2p, &c2s, &c2p})
+            for (int x : *v) t.push_back(x);
         int* d;
         UV_HIP(hipMalloc(&d, t.size() * sizeof(int)));
         UV_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -645,6 +683,7 @@ struct Fwd {
     const half_t* text = nullptr;
     const int *idx_stock = nullptr, *idx_pnp = nullptr, *idx_text = nullptr, *cnt_stock = nullptr, *cnt_pnp = nullptr;
     const float *lw_stock = nullptr, *lw_pnp = nullptr;
+    const int *idx2_stock = nullptr, *idx2_pnp = nullptr, *cnt2_stock = nullptr, *cnt2_pnp = nullptr;   // halo phase (ranks > 0 of a frame shard)
     float* gn_ws = nullptr;
     float* sk_ws = nullptr;        // split-K fp32 partials (UV_SPLITK_WS_BYTES)
     half_t* temb_all = nullptr;    // [B, temb_total]: every resnet's time_emb_proj(SiLU(emb)), one launch per forward
@@ -840,29 +879,64 @@ struct Fwd {
         return UV_OK;
     }
 
-    // frame shard (SURVEY §8e coupling 2): every frame attends to {prev, (cur), first}; the previous frame of this
-    // rank's first frame lives on rank-1 and frame 0 on rank 0.  Packs are [B, N, 2C] (K|V of one frame per branch).
-    int kv_exchange(half_t* qkv, int C, int N) {
-        const long nbytes = (long)B * N * 2 * C * sizeof(half_t);
+    // frame shard (SURVEY §8e coupling 2): every frame attends to {prev, (cur), first}; the previous frame of this rank's first frame lives on
+    // rank-1 and frame 0 on rank 0.  Round 6: what travels is the block's HIDDEN rows of the boundary frame ([B, N, C] fp16 per pack: the input of
+    // norm1 -> to_k | to_v, attention.py:311,375-377; half the bytes of the K|V pack) — the receiver projects (and, inside the PnP window, shifts:
+    // the shift needs per-frame statistics only, pnp_utils.py:114-125) the two halo frames itself — and it travels on a FORKED stream as soon as
+    // proj_in has written the rows, beside this rank's own q|k|v projection, AdaIN shift and the LOCAL phase of its attention:
+    //   kv_post (after proj_in):  pack on s -> fork -> [xstream: multicast to the peers -> raise their flags -> wait for this rank's own flags]
+    //   kv_join (after phase 1):  s waits for the forked stream; the packs are in the inbox slots of comm_ws
+    // A host-callback communicator (torch.distributed / gloo / the host-thread loopback of the tests) is driven from kv_join on s: same packs, serial.
+    struct KvSlots {
+        long o_send = 0, o_first = 0, o_prev = 0, o_rfirst = 0, nbytes = 0;
+        bool forked = false;
+    } kvs;
+    int kv_post(const half_t* h, int C, int N) {
+        kvs = KvSlots();
+        kvs.nbytes = (long)B * N * C * sizeof(half_t);
         // host-callback communicator: 4 slots [send | first | recv prev | recv first].  Native (IPC) communicator: the two receive slots
         // are double-buffered by exchange parity (peers write them without an acknowledgement, comm.hip): 6 slots
         const int nslot = u.native_comm ? 6 : 4;
         const long slot = ((u.comm_ws_bytes - 65536) / nslot) & ~255L;
-        UV_REQUIRE(nbytes <= slot, "kv_exchange: comm workspace too small (%ld B per slot, need %ld)", slot, nbytes);
+        UV_REQUIRE(kvs.nbytes <= slot, "kv_exchange: comm workspace too small (%ld B per slot, need %ld)", slot, kvs.nbytes);
         const long par = u.native_comm ? uv_comm_kv_parity(u.native_comm) : 0;
-        const long o_send = 65536, o_first = o_send + slot, o_prev = o_first + slot * (1 + 2 * par), o_rfirst = o_prev + slot;
-        if (u.rank < u.world - 1) RUN(uv_launch_kv_pack(qkv, 3 * C, C, N, B, F, F - 1, (half_t*)(u.comm_ws + o_send), s));
-        if (u.rank == 0) RUN(uv_launch_kv_pack(qkv, 3 * C, C, N, B, F, 0, (half_t*)(u.comm_ws + o_first), s));
-        int rc = u.kv_exchange(u.comm_user, o_send, o_first, o_prev, o_rfirst, nbytes);
-        if (rc) {
-            uv_set_error("kv_exchange callback failed (%d)", rc);
-            return UV_ERR_STATE;
+        kvs.o_send = 65536;
+        kvs.o_first = kvs.o_send + slot;
+        kvs.o_prev = kvs.o_first + slot * (1 + 2 * par);
+        kvs.o_rfirst = kvs.o_prev + slot;
+        if (u.rank < u.world - 1) RUN(uv_launch_rows_pack(h, C, 0, C, N, B, F, F - 1, (half_t*)(u.comm_ws + kvs.o_send), s));
+        if (u.rank == 0) RUN(uv_launch_rows_pack(h, C, 0, C, N, B, F, 0, (half_t*)(u.comm_ws + kvs.o_first), s));
+        const bool emu = !u.native_comm && u.emu_wire_gbps > 0;
+        if (!u.native_comm && !emu) return UV_OK;
+        hipStream_t x = s;
+        if (u.kv_overlap) {
+            RUN(u.comm_streams());
+            x = u.xstream;
+            UV_HIP(hipEventRecord(u.ev_fork, s));
+            UV_HIP(hipStreamWaitEvent(x, u.ev_fork, 0));
+            kvs.forked = true;
         }
-        if (u.rank > 0) {
-            const long row0 = (long)B * F * N;
-            RUN(uv_launch_kv_unpack((const half_t*)(u.comm_ws + o_prev), qkv, 3 * C, C, N, B, row0, s));
-            RUN(uv_launch_kv_unpack((const half_t*)(u.comm_ws + o_rfirst), qkv, 3 * C, C, N, B, row0 + (long)B * N, s));
+        if (u.native_comm) {
+            RUN(uv_comm_kv_exchange_on(u.native_comm, kvs.o_send, kvs.o_first, kvs.o_prev, kvs.o_rfirst, kvs.nbytes, x));
+        } else {
+            // the slowest transfer of this exchange on a node this box does not have: one pack per link (the first-frame pack reaches every rank over
+            // its own link from rank 0, the halo pack over the link from rank - 1) except on rank 1, whose one link from rank 0 carries both
+            const double us = u.emu_wire_lat_us + (u.rank == 1 ? 2.0 : 1.0) * (double)kvs.nbytes / (u.emu_wire_gbps * 1e3);
+            u.emu_wire_us += us;
+            RUN(uv_launch_delay_us(us, x));
         }
+        if (kvs.forked) UV_HIP(hipEventRecord(u.ev_join, x));
+        return UV_OK;
+    }
+    int kv_join() {
+        if (!u.native_comm) {
+            int rc = u.kv_exchange(u.comm_user, kvs.o_send, kvs.o_first, kvs.o_prev, kvs.o_rfirst, kvs.nbytes);
+            if (rc) {
+                uv_set_error("kv_exchange callback failed (%d)", rc);
+                return UV_ERR_STATE;
+            }
+        }
+        if (kvs.forked) UV_HIP(hipStreamWaitEvent(s, u.ev_join, 0));
         return UV_OK;
     }
 
@@ -950,7 +1024,9 @@ struct Fwd {
         gm = W(b + ".norm1.weight"); bt = W(b + ".norm1.bias");
         if (!gm || !bt) return u.missing_error();
         if (!fold) RUN(uv_launch_layernorm(h, C, t0, C, gm, bt, rows, C, 1e-5f, s));
-        const long extra_rows = u.world > 1 ? (long)2 * B * N : 0;     // received prev-frame + first-frame K/V (frame shard)
+        const bool shard = u.world > 1, halo = shard && u.rank > 0;
+        if (shard) RUN(kv_post(h, C, N));                  // the boundary frames' hidden rows leave now, on the forked stream
+        const long extra_rows = shard ? (long)2 * B * N : 0;     // the halo frames' q|k|v rows behind the local ones: [prev: B x N | first: B x N]
         half_t* qkv = alloc((rows + extra_rows) * 3 * C);
         if (!qkv) return UV_ERR_STATE;
         const bool qs = u.find(b + ".attn1.qkv#fused#qs") != nullptr;      // head_dim 40: scale folded into to_q (finalize)
@@ -958,12 +1034,13 @@ struct Fwd {
         if (fold) RUN(linear(h, C, rows, C, wqkv + "#ln", "", 3 * C, qkv, 3 * C, nullptr, 0, nullptr, 0, nullptr, lnst));
         else RUN(linear(t0, C, rows, C, wqkv, "", 3 * C, qkv, 3 * C));
         const bool registered = pnp_layer && pnp && pnp->registered;
-        if (registered && pnp->idx >= pnp->eta1 && pnp->idx <= pnp->eta2 * 50.f) {
+        const bool shift = registered && pnp->idx >= pnp->eta1 && pnp->idx <= pnp->eta2 * 50.f;
+        float beta = 0.f;
+        if (shift) {
             UV_REQUIRE(B == 3, "PnP attention shift needs the three-branch batch (B=3), got B=%d", B);
-            const float beta = (0.9f - 0.1f) / (pnp->eta1 * 50.f - pnp->eta2 * 50.f) * ((float)pnp->idx - pnp->eta2 * 50.f) + 0.1f;
+            beta = (0.9f - 0.1f) / (pnp->eta1 * 50.f - pnp->eta2 * 50.f) * ((float)pnp->idx - pnp->eta2 * 50.f) + 0.1f;
             RUN(uv_launch_adain_shift(qkv, 3 * C, F, N, C, ad_ws, ad_ws + (long)F * 2 * C, pnp->alpha, beta, pnp->gamma, s));
         }
-        if (u.world > 1) RUN(kv_exchange(qkv, C, N));
         AttnParams ap;
         ap.q = qkv; ap.k = qkv + C; ap.v = qkv + 2 * C;
         ap.ldq = ap.ldkv = 3 * C;
@@ -975,7 +1052,43 @@ struct Fwd {
         ap.BF = x.imgs; ap.Nq = N; ap.Nkv = N; ap.heads = heads; ap.d = d;
         ap.scale_log2e = 1.4426950408889634f / sqrtf((float)d);
         ap.q_prescaled = qs;
+        float* state = nullptr;
+        if (halo) {               // phase 1: the key frames this rank holds; (m, l) per query stays behind for phase 2
+            state = (float*)alloc((long)x.imgs * heads * N * 4);
+            if (!state) return UV_ERR_STATE;
+            ap.state_out = state;
+        }
         RUN(uv_launch_attention(ap, s));
+        if (shard) RUN(kv_join());
+        if (halo) {
+            // the two halo frames: LayerNorm (norm1) of the received hidden rows -> to_k | to_v (all of q|k|v inside the window: the shift kernel works on
+            // the fused rows) -> the AdaIN shift of each frame -> phase 2 over them.  The sender would have computed the same K | V from the same fp16 rows
+            // (with the LayerNorm folded into the GEMM when `fold`: equal up to fp16 rounding of the normalised rows).
+            const long hrows = 2L * B * N;
+            half_t* tn = alloc(hrows * C);
+            if (!tn) return UV_ERR_STATE;
+            RUN(uv_launch_layernorm((const half_t*)(u.comm_ws + kvs.o_prev), C, tn, C, gm, bt, (long)B * N, C, 1e-5f, s));
+            RUN(uv_launch_layernorm((const half_t*)(u.comm_ws + kvs.o_rfirst), C, tn + (long)B * N * C, C, gm, bt, (long)B * N, C, 1e-5f, s));
+            half_t* qh = qkv + rows * 3 * C;
+            half_t* wfull = W(wqkv);
+            if (!wfull) return u.missing_error();
+            if (shift) {
+                RUN(linear(tn, C, hrows, C, wqkv, "", 3 * C, qh, 3 * C));
+                for (int sl = 0; sl < 2; ++sl)            // rows [slot][3 branches][N] = the shift kernel's [3][F = 1][N]
+                    RUN(uv_launch_adain_shift(qh + (long)sl * B * N * 3 * C, 3 * C, 1, N, C, ad_ws, ad_ws + 2L * C, pnp->alpha, beta, pnp->gamma, s));
+            } else {
+                RUN(linear(tn, C, hrows, C, wqkv, "", 2 * C, qh + C, 3 * C, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, wfull + (long)C * C));
+            }
+            free(tn);
+            ap.src_idx = registered ? idx2_pnp : idx2_stock;
+            ap.src_cnt = registered ? cnt2_pnp : cnt2_stock;
+            ap.src_logw = nullptr;
+            ap.state_out = nullptr;
+            ap.state_in = state;
+            RUN(uv_launch_attention(ap, s));
+            ap.state_in = nullptr;
+            free(state);
+        }
         free(qkv);
         // ---- the row-local chain behind the self-attention: to_out + residual -> (norm2) -> attn2 -> to_out + residual -> (norm3) ->
         // GEGLU projection -> FF2 + residual.  Round 4: it runs BAND BY BAND over whole frames when the level is large (64x64 level of
@@ -1184,6 +1297,12 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     f.cnt_pnp = tab + BF_ * 7;
     f.lw_stock = (const float*)(tab + BF_ * 8);
     f.lw_pnp = (const float*)(tab + BF_ * 11);
+    if (world > 1 && rank > 0) {
+        f.idx2_stock = tab + BF_ * 13;
+        f.idx2_pnp = tab + BF_ * 16;
+        f.cnt2_stock = tab + BF_ * 18;
+        f.cnt2_pnp = tab + BF_ * 19;
+    }
     f.gn_ws = (float*)arena.alloc((size_t)uv_groupnorm_workspace_floats(B * F, cfg.norm_num_groups) * sizeof(float));
     f.ad_ws = (float*)arena.alloc((size_t)F * 2 * boc[3] * 2 * sizeof(float) + 1024);
     f.sk_ws = (float*)arena.alloc(UV_SPLITK_WS_BYTES);

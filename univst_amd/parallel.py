@@ -563,13 +563,15 @@ class NullComm:
     runs exactly the kernels, pack/unpack copies and host callbacks of rank r of a w-GPU job — everything except the wire.
     Results are meaningless (nothing is exchanged); only the timing is used."""
 
-    def __init__(self, rank, world, wire_gbps=None, latency_us=3.0):
-        """wire_gbps (``bench.py --emulate-wire``): per-direction rate of ONE xGMI link; every exchange then occupies the stream for the time its
+    def __init__(self, rank, world, wire_gbps=None, latency_us=3.0, kv_in_library=False):
+        """kv_in_library: the K/V exchanges' wire time is issued by the library on its forked stream (``emu_wire_gbps`` option of the UNet handle, round 6);
+        this object then only models the all-reduces' flag round trips.
+        wire_gbps (``bench.py --emulate-wire``): per-direction rate of ONE xGMI link; every exchange then occupies the stream for the time its
         slowest transfer would take, in place — the serial issue order of csrc/comm.hip (pack -> multicast -> raise -> wait on the compute stream).
         The first-frame pack reaches every rank over its own link from rank 0 and the halo pack over the link from rank - 1: one pack per link,
         except on rank 1, whose single link from rank 0 carries both; each GroupNorm all-reduce costs one flag round trip (latency_us)."""
         self.rank, self.world = rank, world
-        self.wire_gbps, self.latency_us = wire_gbps, latency_us
+        self.wire_gbps, self.latency_us, self.kv_in_library = wire_gbps, latency_us, kv_in_library
         self.wire_us = 0.0            # modelled wire time accumulated since the last reset (bench.py reports it per step)
 
     def _delay(self, us):
@@ -584,7 +586,7 @@ class NullComm:
         return [t for _ in range(self.world)]
 
     def halo_and_broadcast(self, send_last, first, recv_prev, recv_first):
-        if self.wire_gbps and self.world > 1:
+        if self.wire_gbps and self.world > 1 and not self.kv_in_library:
             packs = 2 if self.rank == 1 else 1
             self._delay(self.latency_us + packs * send_last.numel() * send_last.element_size() / (self.wire_gbps * 1e3))
 
