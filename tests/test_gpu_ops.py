@@ -479,6 +479,8 @@ def test_attention_two_phase_error_is_rounding_level(nat, heads, d, N, Fl, mode,
     qq = q[:B * Fl]
     c = 1.4426950408889634 / d ** 0.5
 
+    qf = [qq.float()]               # the queries the reference uses (fp32): the raw ones, or the prescaled ones the kernel sees divided by the factor
+
     def ref(rows, want_lse=False):
         out = torch.zeros(B * Fl, N, C, device="cuda")
         lse = torch.full((B * Fl, heads, N), float("nan"), device="cuda")
@@ -487,27 +489,19 @@ def test_attention_two_phase_error_is_rounding_level(nat, heads, d, N, Fl, mode,
                 continue
             kk = torch.cat([k[s_] for s_ in srcs]).float().view(-1, heads, d).transpose(0, 1)
             vv = torch.cat([v[s_] for s_ in srcs]).float().view(-1, heads, d).transpose(0, 1)
-            sc = qq[i].float().view(N, heads, d).transpose(0, 1) @ kk.transpose(1, 2) / d ** 0.5
+            sc = qf[0][i].view(N, heads, d).transpose(0, 1) @ kk.transpose(1, 2) / d ** 0.5
             lse[i] = torch.logsumexp(sc, -1) * 1.4426950408889634
             out[i] = (torch.softmax(sc, -1) @ vv).transpose(0, 1).reshape(N, C)
         return (out, lse) if want_lse else out
-    want = ref(full)
-    want1, lse1 = ref(loc, True)
     if pre:
         buf[:B * Fl, :, :C] = (qq.float() * c).half()
-        qs = buf[:B * Fl, :, :C].float() / c                      # what the kernel sees, for the reference
-        qq_ref = qs
-        want = None
+        qf[0] = buf[:B * Fl, :, :C].float() / c
+    want = ref(full)
+    want1, lse1 = ref(loc, True)
     ti = lambda a, w: torch.tensor([(r + [0] * w)[:w] for r in a], dtype=torch.int32).cuda()
     tc = lambda a: torch.tensor([len(r) for r in a], dtype=torch.int32).cuda()
     W = 3 if mode == "stock" else 2
     tl, tc1, tr, tc2 = ti(loc, W), tc(loc), ti(rem, W), tc(rem)                # (kept alive over the launches)
-    if pre:                     # references on the rounded prescaled q
-        qsave = qq
-        qq = qq_ref.half()
-        want = ref(full)
-        want1, lse1 = ref(loc, True)
-        qq = qsave
     out, st = nat.attention_phase(qq, k, v, tl, tc1, heads, ldq=3 * C, ldkv=3 * C, Nkv=N, C_=C, q_prescaled=bool(pre))
     o1 = out.clone().float()
     ok = ~torch.isnan(lse1)
