@@ -552,11 +552,11 @@ def main():
     shard_check = None
     if world > 1 and not a.no_shard_check:
         # First contact with real multi-GPU hardware happens in the driver's run: before anything is timed, every rank compares ONE
-        # frame-sharded forward (inside the PnP window: K/V exchange, GroupNorm all-reduces) with the unsharded forward of the same
-        # UNet (communicator detached) on the whole clip.  A communicator that fails the check — wrong numbers, a refused mapping, a bounded wait
+        # frame-sharded forward (inside the PnP window: K/V exchange, GroupNorm all-reduces) with the unsharded forward of a SEPARATELY BUILT
+        # native handle of the same weights (FrameShard.fresh_reference) on the whole clip.  A communicator that fails the check — wrong numbers, a refused mapping, a bounded wait
         # that gave up — is replaced: library IPC -> torch.distributed callbacks; if that fails too the run stops with the evidence.
         # (the check lives in the product: parallel.FrameShard.self_check is what video_style_transfer runs under torchrun too;
-        # its reference is the SAME UNet with the communicator detached, on the whole clip)
+        # its reference is a second native handle built from the same module, never attached to a communicator)
         shard_check = shard.self_check(pipe, content_full, style_full, text3)
     sharded = world > 1 or emu is not None
     inv = a.workload.startswith("inversion")
@@ -644,7 +644,8 @@ def main():
             if v["launches"]:
                 classes[k] = dict(ms_per_step=round(v["ms"] / nprof, 3), launches_per_step=round(v["launches"] / nprof, 1),
                                   tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
-                                  gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1))
+                                  gbs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                  **({"im2col_operand_gbs": round(v["expanded_bytes"] / (v["ms"] * 1e-3) / 1e9, 1)} if k.startswith(("conv", "gemm_kernel<*,1>", "gemm_big_kernel<1>")) and v.get("expanded_bytes") else {}))
         mfma = [k for k in prof if k.startswith(("gemm", "attn", "conv")) and prof[k]["launches"]]
         dom = max(mfma, key=lambda k: prof[k]["ms"])
         d = prof[dom]
@@ -653,7 +654,12 @@ def main():
                            "frac": round(ach / PEAK_FP16_TFLOPS, 4), "traffic": None,
                            "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                            "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 2),
-                           "classes": classes}
+                           "classes": classes,
+                           # the class times come from a SECOND pass with a hipEvent pair around every launch: each pair fences its kernel off from its
+                           # neighbours (no overlap of one kernel's tail with the next one's ramp), so their sum exceeds ms_per_step of the timed pass
+                           "classes_sum_ms": round(sum(v["ms_per_step"] for v in classes.values()), 3),
+                           "classes_launches_per_step": round(sum(v["launches_per_step"] for v in classes.values()), 1),
+                           "classes_note": "per-launch event pass, not the timed region: classes_sum_ms - ms_per_step = event fencing (a few us per launch) minus unprofiled kernels"}
         # HBM traffic per launch of that kernel from the committed PMC passes (bench.py cannot collect PMCs itself):
         # profiles/roundN_pmc_traffic.json = rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this command
         # (tools/refresh_profiles.sh; re-collected whenever the kernel changes — the newest round's file wins)

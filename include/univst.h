@@ -402,6 +402,9 @@ int univst_window_store(const float* acc, float weight, uint8_t* dst, int64_t n,
 #define UNIVST_PROFILE_CLASSES 13
 int univst_profile_enable(int on);
 int univst_profile_collect(double* ms, int64_t* count, double* flops, double* bytes, int nclasses);
+/* per class, for the records the LAST univst_profile_collect returned: the EXPANDED operand bytes of the GEMM classes — for a 3x3 conv `bytes` above
+ * charges input + weights + output (what has to cross HBM once), this figure charges the im2col operand M x 9Cin the matrix pipe consumes */
+int univst_profile_collect_aux(double* aux_bytes, int nclasses);
 /* ';'-joined kernel symbols launched in class `cls` since profiling was last switched on (template arguments without spaces, e.g.
  * "gemm_big_kernel<0,4,2>"; classes whose launchers do not name their kernels give ""): bench.py quotes PMC traffic only when every one of them
  * has an entry in the committed counter file */

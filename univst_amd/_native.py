@@ -124,6 +124,7 @@ SIGNATURES = {
     "univst_profile_enable": (_I, [_I]),
     "univst_profile_symbols": (_I, [_I, C.c_char_p, _I]),
     "univst_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+    "univst_profile_collect_aux": (_I, [C.POINTER(C.c_double), _I]),
 }
 
 
@@ -628,8 +629,10 @@ def profile_symbols():
 
 
 def profile_collect():
-    """-> {class: dict(ms=, launches=, flops=, bytes=)} for everything launched since profile_enable(True)."""
+    """-> {class: dict(ms=, launches=, flops=, bytes=, expanded_bytes=)} for everything launched since profile_enable(True)."""
     n = len(PROFILE_CLASSES)
     ms, cnt, fl, by = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
     check(load().univst_profile_collect(ms, cnt, fl, by, n), "profile_collect")
-    return {PROFILE_CLASSES[i]: dict(ms=ms[i], launches=cnt[i], flops=fl[i], bytes=by[i]) for i in range(n)}
+    aux = (C.c_double * n)()
+    check(load().univst_profile_collect_aux(aux, n), "profile_collect_aux")
+    return {PROFILE_CLASSES[i]: dict(ms=ms[i], launches=cnt[i], flops=fl[i], bytes=by[i], expanded_bytes=aux[i]) for i in range(n)}

@@ -439,6 +439,12 @@ int univst_profile_collect(double* ms, int64_t* count, double* flops, double* by
     return rc;
 }
 
+int univst_profile_collect_aux(double* aux_bytes, int ncls) {
+    UV_REQUIRE(aux_bytes && ncls >= 1 && ncls <= 16, "profile_collect_aux: bad arguments");
+    uv_prof_aux(aux_bytes, ncls);
+    return UV_OK;
+}
+
 int64_t univst_maskprop_workspace_bytes(int hw, int Nsrc, int C) { return uv_maskprop_workspace_bytes(hw, Nsrc, C); }
 int univst_maskprop_frame(const float* feat_tar, const float* feat_src, const float* segs_src, float* segs_tar, int hw, int Nsrc,
                           int C, int ncls, float T, int topk, void* ws, void* s) {

@@ -152,9 +152,13 @@ static int comm_allreduce_cb(void* user, int64_t byte_off, int count) {
     univst_comm* c = (univst_comm*)user;
     return uv_comm_allreduce(c, reinterpret_cast<float*>(c->mine + UV_OFF_WS + byte_off), count, c->stream);
 }
-// (round 6: `s` is the stream the whole exchange is issued on — the UNet graph's FORKED stream, so that the multicast and the wait for the
-// peers' packs run beside the rank's own q|k|v projection and the local phase of its attention; unet.hip::Fwd::kv_post)
-static int comm_kv_issue(univst_comm* c, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes, hipStream_t s) {
+// Round 6: the exchange in two halves.  POST (pack already in the send slots): multicast to the peers + raise their flags, on `x` — the UNet graph's FORKED
+// stream, so that the transfer runs beside the rank's own q|k|v projection and the local phase of its attention (unet.hip Fwd::kv_post).  WAIT: the
+// one-block kernel that spins on this rank's own flags, on `s` — the forward's stream, in front of the first kernel that reads the inbox (Fwd::kv_join).
+// The two streams meet only through memory (flags), never through an event per exchange: a cross-queue event costs ~15 us each way on this runtime, sixteen
+// times per step.  Send-slot reuse needs no acknowledgement either: between two posts lie >= 2 GroupNorm all-reduces, and an all-reduce completes only after
+// every peer contributed, which a peer does (stream order) only after it consumed this rank's previous pack.
+static int comm_kv_post(univst_comm* c, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes, hipStream_t x) {
     int rc = comm_check(c);
     if (rc) return rc;
     UV_REQUIRE(nbytes % 16 == 0, "kv_exchange: pack size must be a multiple of 16 bytes");
@@ -169,7 +173,7 @@ static int comm_kv_issue(univst_comm* c, int64_t o_send, int64_t o_first, int64_
         Dsts d;
         d.n = 1;
         d.d[0] = reinterpret_cast<uint4*>(c->peer[c->rank + 1] + UV_OFF_WS + o_prev);
-        hipLaunchKernelGGL(comm_multicast_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(c->mine + UV_OFF_WS + o_send), d, nvec);
+        hipLaunchKernelGGL(comm_multicast_kernel, dim3(grid), dim3(256), 0, x, reinterpret_cast<const uint4*>(c->mine + UV_OFF_WS + o_send), d, nvec);
         fl.f[fl.n++] = flag(c->rank + 1, 0);
     }
     if (c->rank == 0) {                         // the clip's first frame -> every other rank
@@ -179,12 +183,24 @@ static int comm_kv_issue(univst_comm* c, int64_t o_send, int64_t o_first, int64_
             d.d[d.n++] = reinterpret_cast<uint4*>(c->peer[r] + UV_OFF_WS + o_rfirst);
             fl.f[fl.n++] = flag(r, 1);
         }
-        hipLaunchKernelGGL(comm_multicast_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const uint4*>(c->mine + UV_OFF_WS + o_first), d, nvec);
+        hipLaunchKernelGGL(comm_multicast_kernel, dim3(grid), dim3(256), 0, x, reinterpret_cast<const uint4*>(c->mine + UV_OFF_WS + o_first), d, nvec);
     }
-    if (fl.n) hipLaunchKernelGGL(comm_raise_kernel, dim3(1), dim3(64), 0, s, fl, epoch);
-    if (c->rank > 0) hipLaunchKernelGGL(comm_wait_kernel, dim3(1), dim3(2), 0, s, flag(c->rank, 0), flag(c->rank, 1), epoch, c->status);
+    if (fl.n) hipLaunchKernelGGL(comm_raise_kernel, dim3(1), dim3(64), 0, x, fl, epoch);
     UV_LAUNCH_CHECK();
     return UV_OK;
+}
+static int comm_kv_wait(univst_comm* c, hipStream_t s) {          // for the exchange the last comm_kv_post opened
+    if (c->rank == 0) return UV_OK;
+    const unsigned epoch = c->kv_epoch;
+    const int par = epoch & 1;
+    unsigned* f = reinterpret_cast<unsigned*>(c->peer[c->rank] + UV_OFF_FLAGS) + 32 + par * 2;
+    hipLaunchKernelGGL(comm_wait_kernel, dim3(1), dim3(2), 0, s, f, f + 1, epoch, c->status);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+static int comm_kv_issue(univst_comm* c, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes, hipStream_t s) {
+    int rc = comm_kv_post(c, o_send, o_first, o_prev, o_rfirst, nbytes, s);
+    return rc ? rc : comm_kv_wait(c, s);
 }
 
 static int comm_kv_cb(void* user, int64_t o_send, int64_t o_first, int64_t o_prev, int64_t o_rfirst, int64_t nbytes) {
@@ -298,10 +314,29 @@ int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, 
     c->stream = s;
     return comm_kv_cb(c, o_send, o_first, o_prev, o_rfirst, nbytes);
 }
-// the UNet graph's exchange: same packs, issued on `s` (its forked stream) without re-binding the stream of the all-reduces
-int uv_comm_kv_exchange_on(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s) {
+// the UNet graph's exchange in its two halves (see comm_kv_post)
+int uv_comm_kv_post(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t x) {
     UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
-    return comm_kv_issue(c, o_send, o_first, o_prev, o_rfirst, nbytes, s);
+    return comm_kv_post(c, o_send, o_first, o_prev, o_rfirst, nbytes, x);
+}
+int uv_comm_kv_wait(univst_comm* c, hipStream_t s) {
+    UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
+    return comm_kv_wait(c, s);
+}
+// bench.py --emulate-wire: the same flag mechanics against a word of this process (unet.hip: a delay kernel + this raise on the forked stream stand in
+// for a peer's multicast + raise; the forward's stream spins on the word exactly as it does on a peer-raised flag)
+int uv_comm_launch_raise(unsigned* flag, unsigned epoch, hipStream_t s) {
+    Flags fl;
+    fl.n = 1;
+    fl.f[0] = flag;
+    hipLaunchKernelGGL(comm_raise_kernel, dim3(1), dim3(64), 0, s, fl, epoch);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+int uv_comm_launch_wait(const unsigned* flag, unsigned epoch, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(comm_wait_kernel, dim3(1), dim3(2), 0, s, flag, (const unsigned*)nullptr, epoch, status);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
 }
 int uv_comm_barrier(univst_comm* c, hipStream_t s) {             // (the first 64 KiB of the workspace are the all-reduce scratch of both paths)
     return uv_comm_allreduce(c, reinterpret_cast<float*>(c->mine + UV_OFF_WS), 1, s);

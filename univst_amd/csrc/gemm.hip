@@ -1511,6 +1511,18 @@ bool uv_linear_fold_consumer_ok(long M, int N, int K, bool geglu) {
     return small_plan(M, N, K, false, 0, false).splits == 1;
 }
 
+// algorithmic (compulsory) bytes of a launch for the roofline leg: A operand + weights + output (+ the residual it reads).  A 3x3 conv reads its INPUT
+// tensor once — the im2col-expanded operand M x 9Cin (what the matrix pipe consumes, served from LDS / L2 re-reads) is reported beside it as `aux`.
+static inline void uv_gemm_bytes(const GemmParams& p, int mode, double* compulsory, double* expanded) {
+    const double out = (double)p.M * (p.geglu ? p.N / 2 : p.N), w = (double)p.N * p.K, res = p.R ? (double)p.M * p.N : 0.0;
+    const double a_exp = (double)p.M * p.K;
+    double a = a_exp;
+    if (mode == 1 && p.Ho > 0 && p.Wo > 0) a = (double)(p.M / ((long)p.Ho * p.Wo)) * p.Hs * p.Ws * (p.C1 + p.C2);
+    *compulsory = 2.0 * (a + w + out + res);
+    *expanded = 2.0 * (a_exp + w + out + res);
+}
+
+
 int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
     GemmParams p = p0;
     if (mode == 1 && p.tapw == 0) {       // kernel geometry defaults: 3x3 with padding 1, 1x1 without
@@ -1596,8 +1608,9 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
             char sym[48];
             if (use_patch) snprintf(sym, sizeof sym, "conv_patch_kernel<%d>", use192 ? 3 : 4);
             else snprintf(sym, sizeof sym, "gemm_big_kernel<%d,%d,%d>", mode, use192 ? 3 : 4, mode == 0 ? (p.ln_stats ? 2 : (p.stats_out ? 1 : (mmdit_epi ? 3 : 0))) : 0);
-            uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K,
-                          2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream, sym);
+            double by, byx;
+            uv_gemm_bytes(p, mode, &by, &byx);
+            uv_prof_begin(mode == 0 ? UV_CLS_GEMM_BIG : (use_patch ? UV_CLS_CONV_PATCH : UV_CLS_CONV_BIG), 2.0 * p.M * (double)p.N * p.K, by, stream, sym, byx);
             // row-contiguous epilogue through LDS needs 16-byte aligned rows everywhere it touches; it pays for the plain
             // and residual epilogues (-12..19 % at K=320) but not for GEGLU, whose stores are half as many (UNIVST_GEMM_EPI=2 forces it)
             const int epi = big_env().epi;
@@ -1723,8 +1736,9 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
         }
     }
     dim3 grid(nt * q.splits), block(256);
-    uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K,
-                  2.0 * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * (p.geglu ? p.N / 2 : p.N)), stream);
+    double by, byx;
+    uv_gemm_bytes(p, mode, &by, &byx);
+    uv_prof_begin(mode == 0 ? UV_CLS_GEMM : UV_CLS_CONV, 2.0 * p.M * (double)p.N * p.K, by, stream, nullptr, byx);
     if (p.stats_out) {
         hipLaunchKernelGGL((gemm_kernel<5, 0, 4, 1>), grid, block, 0, stream, q);
     } else if (p.ln_stats) {

@@ -227,7 +227,8 @@ enum {
 };
 void uv_prof_enable(int on);
 bool uv_prof_on();
-void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s, const char* sym = nullptr);     // sym: the kernel symbol about to be launched (template arguments without spaces)
+void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s, const char* sym = nullptr, double aux_bytes = 0.0);     // sym: the kernel symbol about to be launched (template arguments without spaces)
 void uv_prof_end(hipStream_t s);
+void uv_prof_aux(double* aux, int ncls);          // per class: the `aux_bytes` sums of the records the LAST uv_prof_collect returned
 int uv_prof_collect(double* ms, long* count, double* flops, double* bytes, int ncls);
 std::string uv_prof_symbols(int cls);           // ';'-joined symbols launched in that class since profiling was switched on

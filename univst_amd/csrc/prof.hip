@@ -10,10 +10,11 @@ namespace {
 struct Rec {
     int cls;
     hipEvent_t a, b;
-    double flops, bytes;
+    double flops, bytes, aux;
 };
 bool g_on = false;
 std::vector<Rec> g_recs;
+double g_aux[UV_NCLS];
 std::set<std::string> g_syms[UV_NCLS];       // kernel symbols launched per class since the last enable(1) (bench.py checks its PMC file against them)
 }  // namespace
 
@@ -29,10 +30,10 @@ std::string uv_prof_symbols(int cls) {
     return out;
 }
 bool uv_prof_on() { return g_on; }
-void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s, const char* sym) {
+void uv_prof_begin(int cls, double flops, double bytes, hipStream_t s, const char* sym, double aux) {
     if (!g_on) return;
     if (sym && cls >= 0 && cls < UV_NCLS) g_syms[cls].insert(sym);
-    Rec r{cls, nullptr, nullptr, flops, bytes};
+    Rec r{cls, nullptr, nullptr, flops, bytes, aux};
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
     (void)hipEventRecord(r.a, s);
@@ -49,6 +50,7 @@ int uv_prof_collect(double* ms, long* count, double* flops, double* bytes, int n
         flops[i] = 0;
         bytes[i] = 0;
     }
+    for (double& a : g_aux) a = 0;
     for (auto& r : g_recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && r.cls < ncls) {
@@ -56,10 +58,14 @@ int uv_prof_collect(double* ms, long* count, double* flops, double* bytes, int n
             count[r.cls] += 1;
             flops[r.cls] += r.flops;
             bytes[r.cls] += r.bytes;
+            if (r.cls >= 0 && r.cls < UV_NCLS) g_aux[r.cls] += r.aux;
         }
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     g_recs.clear();
     return UV_OK;
+}
+void uv_prof_aux(double* aux, int ncls) {
+    for (int i = 0; i < ncls; ++i) aux[i] = i < UV_NCLS ? g_aux[i] : 0.0;
 }

@@ -16,7 +16,10 @@ unsigned uv_comm_kv_parity(const univst_comm* c);
 int uv_comm_poll(univst_comm* c);
 int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s);
 int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
-int uv_comm_kv_exchange_on(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
+int uv_comm_kv_post(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t x);
+int uv_comm_kv_wait(univst_comm* c, hipStream_t s);
+int uv_comm_launch_raise(unsigned* flag, unsigned epoch, hipStream_t s);
+int uv_comm_launch_wait(const unsigned* flag, unsigned epoch, int* status, hipStream_t s);
 int uv_comm_barrier(univst_comm* c, hipStream_t s);
 char* uv_comm_ws(univst_comm* c);
 long uv_comm_ws_bytes(const univst_comm* c);
@@ -83,6 +86,9 @@ struct UNet {
     double emu_wire_us = 0.0;                    // modelled wire time issued since the last univst_unet_query("emu_wire_us")
     hipStream_t xstream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool x_dirty = false;                        // the forked stream carries work of this forward that the forward's stream has not joined yet
+    unsigned* emu_flag = nullptr;                // [0] the emulated inbox flag (device), [1] a status word for the wait kernel
+    unsigned emu_epoch = 0;
     int comm_streams();                          // creates the forked stream + events on first use
 
     ~UNet();

@@ -261,13 +261,15 @@ UNet::~UNet() {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     if (xstream) (void)hipStreamDestroy(xstream);
+    if (emu_flag) (void)hipFree(emu_flag);
 }
 
 int UNet::comm_streams() {
     if (xstream) return UV_OK;
     int lo = 0, hi = 0;                         // (numerically lowest = greatest priority): the exchange's few kernels go ahead of the queued compute
     UV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    UV_HIP(hipStreamCreateWithPriority(&xstream, hipStreamNonBlocking, hi));
+    static const int prio_env = getenv("UNIVST_XSTREAM_PRIO") ? atoi(getenv("UNIVST_XSTREAM_PRIO")) : 1;      // 0: default priority (A/B aid)
+    UV_HIP(hipStreamCreateWithPriority(&xstream, hipStreamNonBlocking, prio_env ? hi : lo));
     UV_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     UV_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     return UV_OK;
@@ -884,12 +886,13 @@ struct Fwd {
     // norm1 -> to_k | to_v, attention.py:311,375-377; half the bytes of the K|V pack) — the receiver projects (and, inside the PnP window, shifts:
     // the shift needs per-frame statistics only, pnp_utils.py:114-125) the two halo frames itself — and it travels on a FORKED stream as soon as
     // proj_in has written the rows, beside this rank's own q|k|v projection, AdaIN shift and the LOCAL phase of its attention:
-    //   kv_post (after proj_in):  pack on s -> fork -> [xstream: multicast to the peers -> raise their flags -> wait for this rank's own flags]
-    //   kv_join (after phase 1):  s waits for the forked stream; the packs are in the inbox slots of comm_ws
+    //   kv_post (after proj_in):  pack on s -> fork (one event) -> [xstream: multicast to the peers -> raise their flags]
+    //   kv_join (after phase 1):  the wait kernel on s spins on this rank's own flags; the packs are then in the inbox slots of comm_ws
+    // The streams meet through the flags only; xstream is joined back into s ONCE, at the end of the forward (UNet::forward).
     // A host-callback communicator (torch.distributed / gloo / the host-thread loopback of the tests) is driven from kv_join on s: same packs, serial.
     struct KvSlots {
         long o_send = 0, o_first = 0, o_prev = 0, o_rfirst = 0, nbytes = 0;
-        bool forked = false;
+        bool emu = false;
     } kvs;
     int kv_post(const half_t* h, int C, int N) {
         kvs = KvSlots();
@@ -906,37 +909,43 @@ struct Fwd {
         kvs.o_rfirst = kvs.o_prev + slot;
         if (u.rank < u.world - 1) RUN(uv_launch_rows_pack(h, C, 0, C, N, B, F, F - 1, (half_t*)(u.comm_ws + kvs.o_send), s));
         if (u.rank == 0) RUN(uv_launch_rows_pack(h, C, 0, C, N, B, F, 0, (half_t*)(u.comm_ws + kvs.o_first), s));
-        const bool emu = !u.native_comm && u.emu_wire_gbps > 0;
-        if (!u.native_comm && !emu) return UV_OK;
+        kvs.emu = !u.native_comm && u.emu_wire_gbps > 0;
+        if (!u.native_comm && !kvs.emu) return UV_OK;
+        const bool sends = u.rank < u.world - 1 || kvs.emu;           // (the last rank posts nothing)
         hipStream_t x = s;
-        if (u.kv_overlap) {
+        if (u.kv_overlap && sends) {
             RUN(u.comm_streams());
             x = u.xstream;
             UV_HIP(hipEventRecord(u.ev_fork, s));
             UV_HIP(hipStreamWaitEvent(x, u.ev_fork, 0));
-            kvs.forked = true;
+            u.x_dirty = true;
         }
         if (u.native_comm) {
-            RUN(uv_comm_kv_exchange_on(u.native_comm, kvs.o_send, kvs.o_first, kvs.o_prev, kvs.o_rfirst, kvs.nbytes, x));
+            RUN(uv_comm_kv_post(u.native_comm, kvs.o_send, kvs.o_first, kvs.o_prev, kvs.o_rfirst, kvs.nbytes, x));
         } else {
             // the slowest transfer of this exchange on a node this box does not have: one pack per link (the first-frame pack reaches every rank over
-            // its own link from rank 0, the halo pack over the link from rank - 1) except on rank 1, whose one link from rank 0 carries both
+            // its own link from rank 0, the halo pack over the link from rank - 1) except on rank 1, whose one link from rank 0 carries both.  The delay
+            // kernel + a raise of this process's own flag word stand in for the peer's multicast + raise
             const double us = u.emu_wire_lat_us + (u.rank == 1 ? 2.0 : 1.0) * (double)kvs.nbytes / (u.emu_wire_gbps * 1e3);
             u.emu_wire_us += us;
+            if (!u.emu_flag) {
+                UV_HIP(hipMalloc((void**)&u.emu_flag, 64));
+                UV_HIP(hipMemsetAsync(u.emu_flag, 0, 64, s));
+                UV_HIP(hipStreamSynchronize(s));
+            }
             RUN(uv_launch_delay_us(us, x));
+            RUN(uv_comm_launch_raise(u.emu_flag, ++u.emu_epoch, x));
         }
-        if (kvs.forked) UV_HIP(hipEventRecord(u.ev_join, x));
         return UV_OK;
     }
     int kv_join() {
-        if (!u.native_comm) {
-            int rc = u.kv_exchange(u.comm_user, kvs.o_send, kvs.o_first, kvs.o_prev, kvs.o_rfirst, kvs.nbytes);
-            if (rc) {
-                uv_set_error("kv_exchange callback failed (%d)", rc);
-                return UV_ERR_STATE;
-            }
+        if (u.native_comm) return uv_comm_kv_wait(u.native_comm, s);
+        int rc = u.kv_exchange(u.comm_user, kvs.o_send, kvs.o_first, kvs.o_prev, kvs.o_rfirst, kvs.nbytes);
+        if (rc) {
+            uv_set_error("kv_exchange callback failed (%d)", rc);
+            return UV_ERR_STATE;
         }
-        if (kvs.forked) UV_HIP(hipStreamWaitEvent(s, u.ev_join, 0));
+        if (kvs.emu && u.rank > 0) RUN(uv_comm_launch_wait(u.emu_flag, u.emu_epoch, (int*)(u.emu_flag + 1), s));
         return UV_OK;
     }
 
@@ -1417,6 +1426,11 @@ int UNet::forward(const half_t* sample, float timestep, const half_t* text, int 
     Act na{n, x.imgs, x.H, x.W, x.C}, y;
     RUN(f.conv(na, nullptr, "conv_out", cfg.out_channels, 9, 1, 0, nullptr, nullptr, &y));
     RUN(uv_launch_nhwc_to_ncfhw(y.p, cfg.out_channels, eps_out, B, cfg.out_channels, F, H * Wd, s));
+    if (x_dirty) {                 // the forked stream's posts of this forward complete before anything the caller queues behind it (and a capture can end)
+        UV_HIP(hipEventRecord(ev_join, xstream));
+        UV_HIP(hipStreamWaitEvent(s, ev_join, 0));
+        x_dirty = false;
+    }
     if (!missing.empty()) return missing_error();
     return UV_OK;
 }

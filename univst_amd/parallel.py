@@ -208,10 +208,37 @@ class FrameShard:
                 self.ensure(unet, max(self._tokens, 1))
         return cm()
 
+    def fresh_reference(self, unet):
+        """context manager: inside the block ``unet`` runs UNSHARDED on a SEPARATELY BUILT native handle (its own weight copy, derived tensors, source
+        tables and arena; no communicator ever attached) — the reference of ``self_check``: an error that depends on the rank or on state of the sharded
+        handle cannot cancel against itself.  The sharded handle is put back, untouched, on exit and the fresh one destroyed."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if self.world == 1:
+                yield
+                return
+            unet._sync_native()
+            keys = ("_native_handle", "_native_sum", "_native_fp", "_native_dirty")
+            saved = {k: unet.__dict__.get(k) for k in keys}
+            unet._native_handle, unet._native_dirty, unet._frame_shard = None, True, None
+            try:
+                yield
+            finally:
+                torch.cuda.synchronize()
+                fresh = unet.__dict__.get("_native_handle")
+                if fresh is not None and fresh is not saved["_native_handle"]:
+                    _native.load().univst_unet_destroy(fresh)
+                for k in keys:
+                    setattr(unet, k, saved[k])
+                unet._frame_shard = self
+        return cm()
+
     def self_check(self, pipe, content_full, style_full, text3, idx: int = 10, t: int = 781, tol: float = 2e-2) -> dict:
         """Every rank compares ONE frame-sharded three-branch forward inside the PnP window (K/V exchange + all 45 GroupNorm
-        all-reduces) with the unsharded forward of the same UNet on the whole clip, before anything that matters runs through the
-        communicator.  A communicator that fails — wrong numbers, a refused IPC mapping, a bounded wait that gave up — is replaced
+        all-reduces) with the unsharded forward of a SEPARATELY BUILT native handle of the same weights on the whole clip (``fresh_reference``),
+        before anything that matters runs through the communicator.  A communicator that fails — wrong numbers, a refused IPC mapping, a bounded wait that gave up — is replaced
         (library IPC -> torch.distributed callbacks) on ALL ranks together; if that one fails too a RuntimeError carries both errors.
         Returns (and keeps in ``self.report``) {"comm", "max_rel_err_vs_unsharded"[, "rejected"]}.  A collective: call on all ranks."""
         if self.world == 1:
@@ -224,7 +251,7 @@ class FrameShard:
         mix = (0.5 * (content_full.float() + style_full.float())).to(torch.float16)
         xf = torch.cat([content_full.to(torch.float16), style_full.to(torch.float16), mix]).contiguous()
         text3 = text3.to(torch.float16).contiguous()
-        with self.detached(unet):
+        with self.fresh_reference(unet):
             if registered:
                 register_time(pipe, idx)
             want = unet(xf, t, encoder_hidden_states=text3).sample[:, :, self.f0:self.f0 + self.local].float()
