@@ -18,16 +18,40 @@ SVD_VAE_CONFIG = dict(in_channels=3, out_channels=3, latent_channels=4, block_ou
                       norm_num_groups=32, scaling_factor=0.18215)
 
 
+# fp32 convolutions as im2col + matmul (tests switch this on for the 16 x 512 x 512 oracle ON THE DEVICE): torch's fp32 convolution path of this ROCm build
+# takes four minutes for that clip, its fp32 matmul seconds.  Same arithmetic (fp32 products, fp32 sums; the summation order differs), checked against
+# F.conv2d in tests/test_oracle_vae.py.  Images are processed in chunks so that the unfolded operand stays below ~2 GB.
+CONV_VIA_MATMUL = False
+
+
+def _conv2d(x, w, b=None, padding=0, stride=1):
+    if not CONV_VIA_MATMUL:
+        return F.conv2d(x, w, b, padding=padding, stride=stride)
+    n, cin, H, W = x.shape
+    cout, _, kh, kw = w.shape
+    Ho, Wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
+    wm = w.reshape(cout, cin * kh * kw)
+    per = max(1, int(2e9 // (cin * kh * kw * Ho * Wo * 4)))
+    out = torch.empty(n, cout, Ho, Wo, device=x.device, dtype=x.dtype)
+    for i in range(0, n, per):
+        cols = F.unfold(x[i:i + per], (kh, kw), padding=padding, stride=stride)          # [m, cin*kh*kw, Ho*Wo]
+        y = torch.matmul(wm, cols)
+        if b is not None:
+            y = y + b[None, :, None]
+        out[i:i + per] = y.view(-1, cout, Ho, Wo)
+    return out
+
+
 def _gn(x, sd, p, groups, eps):
     return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
 
 
 def resnet2d(sd, p, x, groups):
     """ResnetBlock2D(temb_channels=None, eps=1e-6, output_scale_factor=1): norm1 -> silu -> conv1 -> norm2 -> silu -> conv2, + (1x1 conv of) x"""
-    h = F.conv2d(F.silu(_gn(x, sd, p + ".norm1", groups, 1e-6)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
-    h = F.conv2d(F.silu(_gn(h, sd, p + ".norm2", groups, 1e-6)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    h = _conv2d(F.silu(_gn(x, sd, p + ".norm1", groups, 1e-6)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = _conv2d(F.silu(_gn(h, sd, p + ".norm2", groups, 1e-6)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
     if p + ".conv_shortcut.weight" in sd:
-        x = F.conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
+        x = _conv2d(x, sd[p + ".conv_shortcut.weight"], sd[p + ".conv_shortcut.bias"])
     return x + h
 
 
@@ -39,7 +63,7 @@ def frame_conv(x5, w, b):
     y = None
     for t in range(3):
         xt = xp[:, :, t:t + Fr].permute(0, 2, 1, 3, 4).reshape(B * Fr, C, H, W)
-        yt = F.conv2d(xt, w[:, :, t, 0, 0][:, :, None, None])
+        yt = _conv2d(xt, w[:, :, t, 0, 0][:, :, None, None])
         y = yt if y is None else y + yt
     y = y + b[None, :, None, None]
     return y.reshape(B, Fr, -1, H, W).permute(0, 2, 1, 3, 4)
@@ -78,7 +102,7 @@ def attention(sd, p, x, groups):
 def decode(sd, z, num_frames, cfg=SVD_VAE_CONFIG):
     """AutoencoderKLTemporalDecoder.decode(z, num_frames).sample: z [B*F, latent, h, w] -> [B*F, 3, 8h, 8w]"""
     g, boc, L = cfg["norm_num_groups"], cfg["block_out_channels"], cfg["layers_per_block"]
-    x = F.conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    x = _conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
     x = st_resblock(sd, "decoder.mid_block.resnets.0", x, num_frames, g)
     x = attention(sd, "decoder.mid_block.attentions.0", x, g)        # MidBlockTemporalDecoder: zip(resnets[1:], [the one attention])
     if L >= 2:
@@ -88,9 +112,9 @@ def decode(sd, z, num_frames, cfg=SVD_VAE_CONFIG):
             x = st_resblock(sd, f"decoder.up_blocks.{b}.resnets.{l}", x, num_frames, g)
         if b < 3:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = F.conv2d(x, sd[f"decoder.up_blocks.{b}.upsamplers.0.conv.weight"], sd[f"decoder.up_blocks.{b}.upsamplers.0.conv.bias"], padding=1)
+            x = _conv2d(x, sd[f"decoder.up_blocks.{b}.upsamplers.0.conv.weight"], sd[f"decoder.up_blocks.{b}.upsamplers.0.conv.bias"], padding=1)
     x = F.silu(_gn(x, sd, "decoder.conv_norm_out", g, 1e-6))
-    x = F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+    x = _conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
     BF, C, H, W = x.shape
     x5 = x.reshape(BF // num_frames, num_frames, C, H, W).permute(0, 2, 1, 3, 4)
     x5 = frame_conv(x5, sd["decoder.time_conv_out.weight"], sd["decoder.time_conv_out.bias"])
@@ -100,15 +124,15 @@ def decode(sd, z, num_frames, cfg=SVD_VAE_CONFIG):
 def encode_moments(sd, x, cfg=SVD_VAE_CONFIG):
     """AutoencoderKLTemporalDecoder.encode(x).latent_dist.parameters: x [N, 3, H, W] -> [N, 2*latent, H/8, W/8] (mean | logvar)"""
     g, L = cfg["norm_num_groups"], cfg["layers_per_block"]
-    x = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    x = _conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
     for b in range(4):
         for l in range(L):
             x = resnet2d(sd, f"encoder.down_blocks.{b}.resnets.{l}", x, g)
         if b < 3:       # Downsample2D(padding=0): pad right / bottom by one, stride-2 conv without padding
-            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[f"encoder.down_blocks.{b}.downsamplers.0.conv.weight"], sd[f"encoder.down_blocks.{b}.downsamplers.0.conv.bias"], stride=2)
+            x = _conv2d(F.pad(x, (0, 1, 0, 1)), sd[f"encoder.down_blocks.{b}.downsamplers.0.conv.weight"], sd[f"encoder.down_blocks.{b}.downsamplers.0.conv.bias"], stride=2)
     x = resnet2d(sd, "encoder.mid_block.resnets.0", x, g)
     x = attention(sd, "encoder.mid_block.attentions.0", x, g)
     x = resnet2d(sd, "encoder.mid_block.resnets.1", x, g)
     x = F.silu(_gn(x, sd, "encoder.conv_norm_out", g, 1e-6))
-    x = F.conv2d(x, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
-    return F.conv2d(x, sd["quant_conv.weight"], sd["quant_conv.bias"])
+    x = _conv2d(x, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return _conv2d(x, sd["quant_conv.weight"], sd["quant_conv.bias"])

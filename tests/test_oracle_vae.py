@@ -21,6 +21,23 @@ def test_frame_conv_is_conv3d_311():
     assert torch.allclose(vae_ref.frame_conv(x, w, b), F.conv3d(x, w, b, padding=(1, 0, 0)), atol=1e-5)
 
 
+def test_matmul_convolution_path_equals_conv2d():
+    """vae_ref.CONV_VIA_MATMUL (what the 16 x 512 x 512 device oracle of tests/test_gpu_vae.py runs on): im2col + matmul against F.conv2d — 3x3 pad 1,
+    3x3 stride 2 behind the asymmetric pad, 1x1, with and without bias, chunked over images."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    try:
+        vae_ref.CONV_VIA_MATMUL = True
+        for (n, cin, cout, H, W, k, pad, stride, bias) in [(3, 8, 16, 10, 12, 3, 1, 1, True), (2, 16, 8, 9, 9, 3, 0, 2, True), (5, 8, 8, 6, 7, 1, 0, 1, False)]:
+            x, w = torch.randn(n, cin, H, W, generator=g), torch.randn(cout, cin, k, k, generator=g)
+            b = torch.randn(cout, generator=g) if bias else None
+            got = vae_ref._conv2d(x, w, b, padding=pad, stride=stride)
+            want = F.conv2d(x, w, b, padding=pad, stride=stride)
+            assert got.shape == want.shape and (got - want).abs().max() < 1e-4
+    finally:
+        vae_ref.CONV_VIA_MATMUL = False
+
+
 def test_key_list_and_shapes_of_the_svd_vae():
     sd = synth.vae_state_dict(vae_ref.SVD_VAE_CONFIG, device="cpu", dtype=torch.float16)
     # counts of the published class at layers_per_block = 2: 12 decoder up resnets + 2 mid, 8 encoder down resnets + 2 mid

@@ -1635,6 +1635,9 @@ int uv_launch_gemm(const GemmParams& p0, int mode, hipStream_t stream) {
             // GEGLU (round 4): register math + fp16 slab + row-contiguous 16-byte stores (epi_lds = 3); UNIVST_GEMM_EPI=4 keeps the 8-byte register stores (A/B)
             const bool geglu_slab = p.geglu && mode == 0 && epi != 0 && epi != 2 && epi != 4 && p.ldy % 8 == 0 && al16(p.Y) && al16(p.bias) && p.N % 16 == 0;
             if (geglu_slab) q.epi_lds = 3;
+            // the fp32 bias (GroupNorm folded into the linear) exists in the row epilogue through LDS only: a launch that would land on the register
+            // epilogue (misaligned Y / R, UNIVST_GEMM_EPI=0) or on split-K must not drop it silently
+            UV_REQUIRE(!p.bias32 || (q.epi_lds == 1 && bsplits <= 1), "linear: the fp32 bias needs the LDS row epilogue of the direct path (16-byte aligned Y / R / bias rows, no split-K)");
             // (Measured and rejected on this tile, DESIGN.md §4: a 32-wide-k 4-stage DMA ring with counted vmcnt (-10 %), the same
             // with two wave groups staggered by half a k tile + s_setprio (-0..18 %), and a five-phase / two-barriers-per-phase
             // schedule with in-place restaging two k tiles ahead (the guide's 8-phase template on this shape: -3 % linears,

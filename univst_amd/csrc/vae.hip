@@ -58,7 +58,9 @@ __global__ void v_scale_kernel(const half_t* __restrict__ in, half_t* __restrict
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (half_t)((float)in[i] * f);
 }
-// softmax over the rows of S [rows][N] fp16, in place, fp32 arithmetic; one wave per row (N % 8 == 0)
+// softmax over the rows of S [rows][N] fp16, in place, fp32 arithmetic; one wave per row (N % 8 == 0).  The scores arrive ROUNDED TO fp16: a logit beyond
+// 65504 is +inf there and exp(inf - inf) would turn the whole row into NaN (SD-family VAE mid-block activations are large: force_upcast in the stock
+// config) — scores are clamped to the fp16 range on load, so such a row degrades to a tie between its saturated keys instead
 __global__ __launch_bounds__(256) void v_softmax_rows_kernel(half_t* __restrict__ S, long rows, int N) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -68,21 +70,21 @@ __global__ __launch_bounds__(256) void v_softmax_rows_kernel(half_t* __restrict_
     for (int c = lane * 8; c < N; c += 512) {
         const h8 v = *reinterpret_cast<const h8*>(r + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m = fmaxf(m, (float)v[e]);
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fminf((float)v[e], 65504.f));
     }
     m = wave_max(m);
     float l = 0.f;
     for (int c = lane * 8; c < N; c += 512) {
         const h8 v = *reinterpret_cast<const h8*>(r + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) l += __expf((float)v[e] - m);
+        for (int e = 0; e < 8; ++e) l += __expf(fminf((float)v[e], 65504.f) - m);
     }
     l = wave_sum(l);
     const float inv = 1.f / l;
     for (int c = lane * 8; c < N; c += 512) {
         h8 v = *reinterpret_cast<const h8*>(r + c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (half_t)(__expf((float)v[e] - m) * inv);
+        for (int e = 0; e < 8; ++e) v[e] = (half_t)(__expf(fminf((float)v[e], 65504.f) - m) * inv);
         *reinterpret_cast<h8*>(r + c) = v;
     }
 }

@@ -25,6 +25,10 @@ def build_pipeline(pretrained_model_path, weight_dtype=torch.float16, vae_path="
     text_encoder = CLIPTextModel.from_pretrained(pretrained_model_path, subfolder="text_encoder").requires_grad_(False)
     vae = None
     stock = os.environ.get("UNIVST_VAE", "native") == "stock"
+    if not stock and weight_dtype != torch.float16:
+        # the native VAE computes and returns fp16 only (univst_amd/vae.py): a pipeline asked for another dtype keeps the stock module, as the reference does
+        print(f"[univst_amd] weight_dtype {weight_dtype}: the native temporal VAE is fp16-only, using the stock AutoencoderKLTemporalDecoder", flush=True)
+        stock = True
     if not stock and os.path.isdir(os.path.join(vae_path, "vae")):
         vae = NativeTemporalVAE.from_pretrained(vae_path, subfolder="vae")
     if vae is None:
