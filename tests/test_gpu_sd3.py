@@ -683,6 +683,90 @@ def test_bench_sd3_two_ranks_end_to_end():
 # registered.  Frames reduced to 3 branches x 3 so the fp32 oracle fits on the device next to the model (2.2 B parameters twice): the
 # geometry per frame — ragged 256 x 320 tiles of the 1536 / 4608 / 6144-wide linears, attn_pp64_kernel over 3 x 4096 + 333 keys,
 # merged duplicate sources at f = 0, 1 — is config 5's.
+def _sd35_medium_for_tests():
+    from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+    from univst_amd.backbones.video_diffusion_sd3.models.transformer_3D_model import sd35_medium
+    torch.manual_seed(1905)
+    with torch.device("cuda"):
+        m = sd35_medium()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("norm_q.weight") or n.endswith("norm_k.weight") or "norm_added" in n:
+                p.copy_(1.0 + 0.2 * torch.randn_like(p))
+    m = m.half().requires_grad_(False)
+    pnp_utils.register_spatial_attention_pnp(types.SimpleNamespace(transformer=m), eta1=0.0, eta2=0.6)
+    return m
+
+
+def _sd35_config5_inputs(Fc=16, hl=128):
+    g = torch.Generator().manual_seed(7)
+    lat = torch.randn(3 * Fc, 16, hl, hl, generator=g).half()
+    lat[2 * Fc:] = lat[2 * Fc:] * 1.2 + 0.1
+    enc = torch.randn(1, 77 + 256, 4096, generator=g).half().expand(3 * Fc, -1, -1).contiguous()
+    pooled = torch.randn(1, 2048, generator=g).half().expand(3 * Fc, -1).contiguous()
+    return lat, enc, pooled, torch.tensor([437.0])
+
+
+def _sd35_config5_rank(rank, world, port, q):
+    import os
+    import traceback
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from univst_amd.parallel import Sd3FrameShard
+        m = _sd35_medium_for_tests()
+        lat, enc, pooled, t = _sd35_config5_inputs()
+        sh = Sd3FrameShard(rank, world, 16).attach(m, tokens=64 * 64)
+        v = m(hidden_states=sh.slice_branches(lat).cuda(), timestep=t.cuda().expand(3 * sh.local), encoder_hidden_states=sh.slice_branches(enc).cuda(),
+              pooled_projections=sh.slice_branches(pooled).cuda(), return_dict=False, joint_attention_kwargs={"idx": 12})[0]
+        torch.cuda.synchronize()
+        q.put((rank, v.float().cpu().numpy(), None))          # this rank's frames of the three branches [3 * local, 16, h, w]
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_sd35_medium_config5_size_16_frames_shard_equals_unsharded(nat):
+    """BASELINE config 5 at ITS OWN size — SD3.5-medium, 1024 px, 16 frames per branch, three branches, inside the shift window — once unsharded and once
+    frame-sharded over two PROCESSES through the library's IPC communicator (eight frames per rank; round 6: the exchange posted on the forked stream
+    before the text projections, the joint attention in two phases on rank 1): finite, and shard == unsharded up to fp16 summation order.  (The
+    3-frame case of test_sd35_medium_three_branch_forward_at_1024px_vs_oracle pins the numbers to the fp32 oracle; the oracle at 16 frames would be
+    12621 x 4429 fp32 scores x 24 heads x 48 frames.)"""
+    import socket
+    import torch.multiprocessing as mp
+    m = _sd35_medium_for_tests()
+    lat, enc, pooled, t = _sd35_config5_inputs()
+    want = m(hidden_states=lat.cuda(), timestep=t.cuda().expand(48), encoder_hidden_states=enc.cuda(), pooled_projections=pooled.cuda(),
+             return_dict=False, joint_attention_kwargs={"idx": 12})[0].float().cpu()
+    assert torch.isfinite(want).all()
+    del m
+    torch.cuda.empty_cache()
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_sd35_config5_rank, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = {}
+    for _ in range(2):
+        rank, out, err = q.get(timeout=900)
+        assert err is None, err
+        res[rank] = torch.from_numpy(out)
+    for pr in procs:
+        pr.join(timeout=120)
+    w5 = want.view(3, 16, *want.shape[1:])
+    for r in range(2):
+        got = res[r].view(3, 8, *want.shape[1:])
+        mx, rms = errs(got, w5[:, 8 * r:8 * r + 8])
+        assert torch.isfinite(got).all() and mx < 6e-3 and rms < 1.5e-3, (r, mx, rms)
+
+
 @pytest.mark.parametrize("idx", [12, 40])
 def test_sd35_medium_three_branch_forward_at_1024px_vs_oracle(nat, idx):
     """one three-branch MM-DiT forward of the transfer loop inside (idx 12) / outside (idx 40) the shift window vs

@@ -123,6 +123,8 @@ struct univst_comm {
     unsigned ar_epoch = 0, kv_epoch = 0;
     int* status = nullptr;                                   // host-mapped: 0 ok, 100 + r / 200 + k = gave up waiting
     hipStream_t stream = nullptr;                            // the stream of the forward() in flight (callbacks carry none)
+    hipStream_t xstream = nullptr;                           // forked stream of callers without one of their own (the SD3 joint attention: uv_comm_fork)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static int comm_check(univst_comm* c) {
@@ -278,6 +280,9 @@ int univst_comm_destroy(univst_comm* c) {
         if (c->opened[r]) (void)hipIpcCloseMemHandle(c->peer[r]);
     if (c->mine) (void)hipFree(c->mine);
     if (c->status) (void)hipHostFree(c->status);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     delete c;
     return UV_OK;
 }
@@ -322,6 +327,28 @@ int uv_comm_kv_post(univst_comm* c, long o_send, long o_first, long o_prev, long
 int uv_comm_kv_wait(univst_comm* c, hipStream_t s) {
     UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
     return comm_kv_wait(c, s);
+}
+// a forked stream for callers that have none (csrc/sd3.hip): *x runs after everything queued on s so far; uv_comm_join makes s wait for what x holds
+int uv_comm_fork(univst_comm* c, hipStream_t s, hipStream_t* x) {
+    static const int ov = getenv("UNIVST_KV_OVERLAP") ? atoi(getenv("UNIVST_KV_OVERLAP")) : 1;
+    if (!ov) {
+        *x = s;
+        return UV_OK;
+    }
+    if (!c->xstream) {
+        UV_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+        UV_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        UV_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    UV_HIP(hipEventRecord(c->ev_fork, s));
+    UV_HIP(hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
+    *x = c->xstream;
+    return UV_OK;
+}
+int uv_comm_join(univst_comm* c, hipStream_t s) {
+    UV_HIP(hipEventRecord(c->ev_join, c->xstream));
+    UV_HIP(hipStreamWaitEvent(s, c->ev_join, 0));
+    return UV_OK;
 }
 // bench.py --emulate-wire: the same flag mechanics against a word of this process (unet.hip: a delay kernel + this raise on the forked stream stand in
 // for a peer's multicast + raise; the forward's stream spins on the word exactly as it does on a peer-raised flag)

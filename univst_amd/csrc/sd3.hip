@@ -153,8 +153,11 @@ __global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv
 // clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): the frame itself, once.
 // Frame shard (world > 1): this rank holds frames [rank*clip, (rank+1)*clip) of every branch; the clip's first frame and the frame
 // before this rank's first one arrive in the row blocks B + 2b (first) and B + 2b + 1 (previous) of branch b.
+// phase (round 6, ranks > 0 of a frame shard: the two-phase attention of csrc/attention.hip): 0 = the whole key set; 1 = only the sources this rank
+// HOLDS (the frame itself and, from its second local frame on, the previous one); 2 = only the halo sources (the clip's first frame and, for the rank's
+// first local frame, the frame before it — merged into one source of weight 2 where they are the same frame).
 __global__ void sd3_index_kernel(int B, int clip, int rank, int* __restrict__ src_idx, int* __restrict__ x_idx, int* __restrict__ cnt,
-                                 float* __restrict__ logw) {
+                                 float* __restrict__ logw, int phase) {
     const int bf = blockIdx.x * blockDim.x + threadIdx.x;
     if (bf >= B) return;
     x_idx[bf] = bf;
@@ -170,6 +173,24 @@ __global__ void sd3_index_kernel(int B, int clip, int rank, int* __restrict__ sr
     const int gf = rank * clip + f;                                   // frame index in the whole clip
     const int first = rank == 0 ? b * clip : B + 2 * b;               // row block holding the clip's first frame
     const int prev = f > 0 ? bf - 1 : B + 2 * b + 1;                  // (gf >= 1) row block of frame gf - 1
+    if (phase == 1) {                       // rank > 0: gf >= 1
+        cnt[bf] = f > 0 ? 2 : 1;
+        if (f > 0) si[0] = prev;            // [prev, cur] / [cur]
+        return;
+    }
+    if (phase == 2) {
+        si[0] = first;
+        if (gf == 1) {                      // 'first' and gf - 1 are the same frame
+            cnt[bf] = 1;
+            lw[0] = 1.f;
+        } else if (f == 0) {
+            cnt[bf] = 2;
+            si[1] = prev;
+        } else {
+            cnt[bf] = 1;
+        }
+        return;
+    }
     if (gf == 0) {
         cnt[bf] = 1;
         lw[0] = 1.5849625007211562f;          // log2(3)
@@ -458,14 +479,18 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
     const size_t n_half = (size_t)(rows_i + rows_t) * 4 * C + (size_t)rows_x * 3 * C;
     const size_t n_stat = shift ? (size_t)4 * Fb * 2 * C + (size_t)2 * Fb * 2 * heads : 0;
     char* ws = nullptr;
-    const size_t bytes = n_half * sizeof(half_t) + n_stat * sizeof(float) + (size_t)B * 8 * sizeof(int) + 1024;      // src_idx[3B] x_idx[B] cnt[B] logw[3B]
+    const bool two_phase = sharded && rank > 0;              // round 6: the keys this rank holds first, the halo frames continue from the softmax state
+    const size_t n_state = two_phase ? (size_t)(rows_i + rows_t) * heads * 2 : 0;
+    const size_t bytes = n_half * sizeof(half_t) + (n_stat + n_state) * sizeof(float) + (size_t)B * 8 * sizeof(int) + 1024;      // src_idx[3B] x_idx[B] cnt[B] logw[3B]
     UV_HIP(hipMallocAsync((void**)&ws, bytes, s));
     half_t* qkv_i = (half_t*)ws;
     half_t* qkv_t = qkv_i + (rows_i + rows_x) * 3 * C;
     half_t* o_i = qkv_t + rows_t * 3 * C;
     half_t* o_t = o_i + rows_i * C;
     float* st = (float*)(((uintptr_t)(o_t + rows_t * C) + 255) & ~(uintptr_t)255);
-    int* tab = (int*)(st + n_stat);
+    float* state_i = st + n_stat;
+    float* state_t = state_i + (two_phase ? (size_t)rows_i * heads * 2 : 0);
+    int* tab = (int*)(st + n_stat + n_state);
     auto H = [](const void* p) { return (const half_t*)p; };
     int rc = UV_OK;
     auto body = [&]() -> int {
@@ -496,6 +521,36 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         if (shift) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0); window test + beta come from the caller, evaluated in double
             RUN(univst_sd3_adain_shift(qkv_i, 3 * C, Fb, N, C, heads, 0.8f, beta, 2.0f, st, s));
         }
+        // ---- frame shard, first half of the exchange (round 6: BEFORE the text stream's projections, on the communicator's forked stream): K | V of this
+        // rank's last frame of every branch -> rank + 1, of the clip's first frame (rank 0) -> every rank; after the AdaIN shift, which rewrites the
+        // stylised branch's K / V.  Pack [branch][N][2C] in the communicator's workspace: 64 KiB of all-reduce scratch, then send | first |
+        // inbox[parity][previous, first].  The transfer then runs beside the text projections and the attention over the keys this rank holds.
+        long o_prev = 0, o_rfirst = 0;
+        const long cpn = (long)N * (2 * C / 8);
+        const unsigned cgrid = (unsigned)((cpn + 255) / 256);
+        char* ws_c = sharded ? uv_comm_ws(comm) : nullptr;
+        hipStream_t xs = s;
+        if (sharded) {
+            const long pack = (((long)nbr * N * 2 * C * (long)sizeof(half_t)) + 255) & ~255L;
+            UV_REQUIRE(65536 + 6 * pack <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
+                       "6 K/V packs of %ld bytes", uv_comm_ws_bytes(comm), pack);
+            const long o_send = 65536, o_first = 65536 + pack;
+            const unsigned par = uv_comm_kv_parity(comm);
+            o_prev = 65536 + (2 + 2 * par) * pack;
+            o_rfirst = o_prev + pack;
+            for (int b = 0; b < nbr; ++b) {
+                const half_t* last = qkv_i + ((long)(b * clip_length + clip_length - 1) * N) * 3 * C + C;
+                if (rank < world - 1)
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, last, (long)3 * C, (half_t*)(ws_c + o_send) + (long)b * N * 2 * C,
+                                       (long)2 * C, (long)N, 2 * C / 8);
+                if (rank == 0)
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, qkv_i + ((long)b * clip_length * N) * 3 * C + C, (long)3 * C,
+                                       (half_t*)(ws_c + o_first) + (long)b * N * 2 * C, (long)2 * C, (long)N, 2 * C / 8);
+            }
+            UV_LAUNCH_CHECK();
+            if (rank < world - 1) RUN(uv_comm_fork(comm, s, &xs));       // (the last rank posts nothing)
+            RUN(uv_comm_kv_post(comm, o_send, o_first, o_prev, o_rfirst, (long)nbr * N * 2 * C * (long)sizeof(half_t), xs));
+        }
         if (enc) {
             const half_t* e = H(enc);
             if (fused3(w->add_q, w->add_k, w->add_v, w->add_q_bias, w->add_k_bias, w->add_v_bias)) {
@@ -510,56 +565,60 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             else if (w->norm_added_q) RUN(univst_rmsnorm_heads(qkv_t, 3 * C, rows_t, heads, head_dim, w->norm_added_q, rms_eps, s));
             else if (w->norm_added_k) RUN(univst_rmsnorm_heads(qkv_t + C, 3 * C, rows_t, heads, head_dim, w->norm_added_k, rms_eps, s));
         }
-        if (sharded) {
-            // K | V of this rank's last frame of every branch -> rank + 1, of the clip's first frame (rank 0) -> every rank; after the
-            // AdaIN shift, which rewrites the stylised branch's K / V.  Pack [branch][N][2C] in the communicator's workspace: 64 KiB of
-            // all-reduce scratch, then send | first | inbox[parity][previous, first].
-            const long pack = (((long)nbr * N * 2 * C * (long)sizeof(half_t)) + 255) & ~255L;
-            UV_REQUIRE(65536 + 6 * pack <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
-                       "6 K/V packs of %ld bytes", uv_comm_ws_bytes(comm), pack);
-            char* ws_c = uv_comm_ws(comm);
-            const long o_send = 65536, o_first = 65536 + pack;
-            const unsigned par = uv_comm_kv_parity(comm);
-            const long o_prev = 65536 + (2 + 2 * par) * pack, o_rfirst = o_prev + pack;
-            const long cpn = (long)N * (2 * C / 8);
-            const unsigned cgrid = (unsigned)((cpn + 255) / 256);
-            for (int b = 0; b < nbr; ++b) {
-                const half_t* last = qkv_i + ((long)(b * clip_length + clip_length - 1) * N) * 3 * C + C;
-                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, last, (long)3 * C, (half_t*)(ws_c + o_send) + (long)b * N * 2 * C,
-                                   (long)2 * C, (long)N, 2 * C / 8);
-                if (rank == 0)
-                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, qkv_i + ((long)b * clip_length * N) * 3 * C + C, (long)3 * C,
-                                       (half_t*)(ws_c + o_first) + (long)b * N * 2 * C, (long)2 * C, (long)N, 2 * C / 8);
-            }
-            RUN(uv_comm_kv_exchange(comm, o_send, o_first, o_prev, o_rfirst, (long)nbr * N * 2 * C * (long)sizeof(half_t), s));
-            if (rank > 0) {
-                for (int b = 0; b < nbr; ++b) {
-                    half_t* xf = qkv_i + (rows_i + (long)(2 * b) * N) * 3 * C + C;
-                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_rfirst) + (long)b * N * 2 * C, (long)2 * C,
-                                       xf, (long)3 * C, (long)N, 2 * C / 8);
-                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_prev) + (long)b * N * 2 * C, (long)2 * C,
-                                       xf + (long)N * 3 * C, (long)3 * C, (long)N, 2 * C / 8);
-                }
-            }
-            RUN(uv_comm_barrier(comm, s));        // nobody starts the next exchange before every rank has unpacked this one
-        }
-        hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, rank, tab, tab + 3 * B, tab + 4 * B,
-                           (float*)(tab + 5 * B));
-        UV_LAUNCH_CHECK();
         AttnParams a;
         a.k = qkv_i + C; a.v = qkv_i + 2 * C; a.ldkv = 3 * C;
         a.src_idx = tab; a.nsrc = 3; a.src_cnt = tab + 4 * B; a.src_logw = (const float*)(tab + 5 * B); a.BF = B; a.Nkv = N; a.heads = heads; a.d = head_dim;
         a.scale_log2e = qscale;
         a.q_prescaled = presc ? 1 : 0;
-        if (enc) { a.kx = qkv_t + C; a.vx = qkv_t + 2 * C; a.ldkv_x = 3 * C; a.Nkv_x = Nt; a.x_idx = tab + 3 * B; }
-        a.q = qkv_i; a.ldq = 3 * C; a.Nq = N; a.o = o_i; a.ldo = C;
-        RUN(uv_launch_attention(a, s));                                  // image queries over [first | prev | cur] ++ text keys
+        auto index = [&](int phase) {
+            hipLaunchKernelGGL(sd3_index_kernel, dim3((unsigned)((B + 127) / 128)), dim3(128), 0, s, B, clip_length, rank, tab, tab + 3 * B, tab + 4 * B,
+                               (float*)(tab + 5 * B), phase);
+        };
+        auto attend = [&](int phase) -> int {                              // image queries, then text queries, over the key set of `phase`
+            if (enc && phase != 2) { a.kx = qkv_t + C; a.vx = qkv_t + 2 * C; a.ldkv_x = 3 * C; a.Nkv_x = Nt; a.x_idx = tab + 3 * B; }
+            else { a.kx = nullptr; a.vx = nullptr; a.x_idx = nullptr; a.Nkv_x = 0; }
+            a.q = qkv_i; a.ldq = 3 * C; a.Nq = N; a.o = o_i; a.ldo = C;
+            a.state_out = phase == 1 ? state_i : nullptr;
+            a.state_in = phase == 2 ? state_i : nullptr;
+            RUN(uv_launch_attention(a, s));                                  // image queries over [first | prev | cur] ++ text keys
+            if (enc) {
+                a.q = qkv_t; a.Nq = Nt; a.o = o_t;
+                a.state_out = phase == 1 ? state_t : nullptr;
+                a.state_in = phase == 2 ? state_t : nullptr;
+                RUN(uv_launch_attention(a, s));                              // text queries over the same key set
+            }
+            return UV_OK;
+        };
+        if (!two_phase) {
+            index(0);
+            UV_LAUNCH_CHECK();
+            RUN(attend(0));
+        } else {
+            index(1);
+            UV_LAUNCH_CHECK();
+            RUN(attend(1));                                                  // the keys this rank holds ++ the text keys, while the halo is on the wire
+            RUN(uv_comm_kv_wait(comm, s));
+            for (int b = 0; b < nbr; ++b) {
+                half_t* xf = qkv_i + (rows_i + (long)(2 * b) * N) * 3 * C + C;
+                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_rfirst) + (long)b * N * 2 * C, (long)2 * C,
+                                   xf, (long)3 * C, (long)N, 2 * C / 8);
+                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_prev) + (long)b * N * 2 * C, (long)2 * C,
+                                   xf + (long)N * 3 * C, (long)3 * C, (long)N, 2 * C / 8);
+            }
+            index(2);
+            UV_LAUNCH_CHECK();
+            RUN(attend(2));                                                  // the halo frames: continues from the (m, l) state, merges
+        }
+        if (sharded) {
+            // nobody starts the next exchange before every rank has consumed this one.  It also retires the forked stream without an event: the barrier
+            // completes only after the peers consumed the packs, i.e. after this rank's multicast and raise have run
+            RUN(uv_comm_barrier(comm, s));
+            (void)xs;
+        }
         // (gr: the block's gated residual rides in the out-projection's epilogue: out = res + gate[b] (.) to_out(o))
         RUN(linear(o_i, C, rows_i, C, H(w->to_out), H(w->to_out_bias), Cin, (half_t*)out_img, Cin, s, gr ? H(gr->res_img) : nullptr,
                    gr ? H(gr->gate_img) : nullptr, gr ? gr->ld_gate_img : 0, N));
         if (enc) {
-            a.q = qkv_t; a.Nq = Nt; a.o = o_t;
-            RUN(uv_launch_attention(a, s));                              // text queries over the same key set
             if (w->to_add_out)
                 RUN(linear(o_t, C, rows_t, C, H(w->to_add_out), H(w->to_add_out_bias), Cin, (half_t*)out_txt, Cin, s, gr ? H(gr->res_txt) : nullptr,
                            gr ? H(gr->gate_txt) : nullptr, gr ? gr->ld_gate_txt : 0, Nt));

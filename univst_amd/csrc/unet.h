@@ -18,6 +18,8 @@ int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s);
 int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
 int uv_comm_kv_post(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t x);
 int uv_comm_kv_wait(univst_comm* c, hipStream_t s);
+int uv_comm_fork(univst_comm* c, hipStream_t s, hipStream_t* x);
+int uv_comm_join(univst_comm* c, hipStream_t s);
 int uv_comm_launch_raise(unsigned* flag, unsigned epoch, hipStream_t s);
 int uv_comm_launch_wait(const unsigned* flag, unsigned epoch, int* status, hipStream_t s);
 int uv_comm_barrier(univst_comm* c, hipStream_t s);
