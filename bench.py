@@ -489,6 +489,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = min(local, torch.cuda.device_count() - 1)      # (bring-up: several ranks may share one GPU with --backend gloo)
         torch.cuda.set_device(local)
+        if -(-world // torch.cuda.device_count()) > 4 and "UNIVST_KV_OVERLAP" not in os.environ:
+            # more than four ranks on ONE device: their forward + forked queues oversubscribe its hardware queues and a spinning wait kernel can starve a
+            # peer's unmapped queue until a bounded wait gives up — the exchange stays on the forward's stream there (a bring-up case: one rank per GPU forks)
+            os.environ["UNIVST_KV_OVERLAP"] = "0"
         import datetime
         tmo = datetime.timedelta(seconds=300)        # a rank that died leaves its peers in a collective: fail in minutes, not in NCCL's default 10
         if a.backend == "nccl":

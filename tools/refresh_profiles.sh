@@ -5,7 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-5}
+ROUND=${ROUND:-6}
 O=$R/gpurun_out/profiles_new
 rm -rf $O && mkdir -p $O/raw
 cd $R
@@ -22,9 +22,18 @@ python bench.py --frames 32 --emulate-rank 0/8 --no-cpu-baseline > $O/round${ROU
 python bench.py --frames 32 --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 7/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank7of8.json 2>> $O/raw/bench.err
 python bench.py --emulate-rank 1/8 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8.json 2>> $O/raw/bench.err
-# the same ranks with the wire modelled (round 5): every exchange keeps the stream busy for pack bytes / 64 GB/s per link, serial as comm.hip issues them
+# the same ranks with the wire modelled at 64 GB/s per link.  Round 6: the delay sits on the FORKED stream the multicast really runs on (unet.hip kv_post) and the
+# forward's stream spins on a self-raised flag; _serial = the same packs issued on the forward's own stream (UNIVST_KV_OVERLAP=0: round 5's order), _inf = a wire that
+# costs nothing (what the fork / flag machinery itself costs)
 python bench.py --emulate-rank 1/8 --emulate-wire 64 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f16_rank1of8_wire64.json 2>> $O/raw/bench.err
 python bench.py --frames 32 --emulate-rank 1/8 --emulate-wire 64 --no-cpu-baseline > $O/round${ROUND}_bench_emulated_f32_rank1of8_wire64.json 2>> $O/raw/bench.err
+python bench.py --frames 32 --emulate-rank 4/8 --emulate-wire 64 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_emulated_f32_rank4of8_wire64.json 2>> $O/raw/bench.err
+UNIVST_KV_OVERLAP=0 python bench.py --emulate-rank 1/8 --emulate-wire 64 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_emulated_f16_rank1of8_wire64_serial.json 2>> $O/raw/bench.err
+UNIVST_KV_OVERLAP=0 python bench.py --frames 32 --emulate-rank 1/8 --emulate-wire 64 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_emulated_f32_rank1of8_wire64_serial.json 2>> $O/raw/bench.err
+python bench.py --frames 32 --emulate-rank 1/8 --emulate-wire 10000,0 --no-cpu-baseline --no-profile > $O/round${ROUND}_bench_emulated_f32_rank1of8_wire_inf.json 2>> $O/raw/bench.err
+# the emulated F = 32 rank by kernel symbol x grid size (where a rank's step goes)
+rocprofv3 --kernel-trace --output-format csv -d $O/raw/trace_rank -- python bench.py --frames 32 --emulate-rank 1/8 --emulate-wire 64 --steps 10 --warmup 2 --no-cpu-baseline --no-profile > $O/raw/trace_rank.log 2>&1
+python tools/step_shapes.py $O/raw/trace_rank 12 > $O/round${ROUND}_emulated_f32_rank_shapes.txt 2>&1
 python bench.py --workload vae_decode > $O/round${ROUND}_bench_vae_decode.json 2>> $O/raw/bench.err
 # the linears of a step by shape, each next to max(flops / 1 200 TF, bytes / 5 TB/s); the fused text cross-attention against the three launches it replaces
 python tools/bench_linears_step.py > $O/round${ROUND}_linears_by_shape.txt 2>> $O/raw/bench.err
