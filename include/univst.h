@@ -78,13 +78,16 @@ int univst_unet_forward(univst_unet* h, const void* sample, float timestep, cons
                         int W, int text_len, const univst_pnp* pnp, void* eps_out, void* feat_out, int ft_index,
                         void* stream);
 /* frame-sharded multi-GPU: this rank holds frames [rank*F, (rank+1)*F) of a clip of world*F frames
- * for ALL branches.  comm_ws is a caller-owned device workspace (>= 64 KiB + 4 x the largest K/V frame pack =
- * B*N*2C fp16); the callbacks are invoked on the host while forward() enqueues work and must enqueue the
- * collective on the SAME stream forward() was given (RCCL through torch.distributed on the Python side):
+ * for ALL branches.  comm_ws is a caller-owned device workspace (>= 64 KiB + 4 x the largest frame pack); the callbacks are invoked on the
+ * host while forward() enqueues work and must enqueue the collective on the SAME stream forward() was given (RCCL through
+ * torch.distributed on the Python side):
  *   allreduce(user, byte_off, n)         : in-place SUM over ranks of n fp32 at comm_ws + byte_off  (5-D GroupNorm)
  *   kv_exchange(user, off_send_last, off_first, off_recv_prev, off_recv_first, nbytes):
  *        rank 0 broadcasts [off_first, +nbytes) (others receive it at off_recv_first); every rank r < world-1
- *        sends [off_send_last, +nbytes) to r+1, every rank r > 0 receives it at off_recv_prev  (sparse-causal K/V) */
+ *        sends [off_send_last, +nbytes) to r+1, every rank r > 0 receives it at off_recv_prev  (sparse-causal attention, attention.py:384-413).
+ * ABI 3 (round 6): a pack is the transformer block's HIDDEN rows of the boundary frame of every branch, [B, N, C] fp16 (the input of norm1 ->
+ * to_k | to_v; until ABI 2: the K | V rows, [B, N, 2C]); the receiving rank projects (and, inside the PnP window, shifts) the two halo frames
+ * itself and runs the attention in two phases (univst_attention_phase).  The callback only moves bytes and is invoked between the phases. */
 typedef int (*univst_allreduce_fn)(void* user, int64_t byte_off, int count_f32);
 typedef int (*univst_kv_exchange_fn)(void* user, int64_t off_send_last, int64_t off_first, int64_t off_recv_prev,
                                      int64_t off_recv_first, int64_t nbytes);
@@ -96,7 +99,7 @@ int univst_unet_set_comm(univst_unet* h, int rank, int world, void* comm_ws, int
  * as device-side peer writes + flags on the caller's stream — no host callbacks, so a forward() is a pure stream of kernels.
  * Replaces what the reference would need for `attention.py:384-413` / the 5-D GroupNorms of `resnet.py:338,369` across GPUs (the
  * reference itself is single-GPU).  Bring-up sequence on every rank:
- *   univst_comm_create(rank, world, ws_bytes, &c)      ws_bytes >= 64 KiB + 6 x the largest K/V frame pack (B*N*2C fp16)
+ *   univst_comm_create(rank, world, ws_bytes, &c)      ws_bytes >= 64 KiB + 6 x the largest frame pack (B*N*C fp16 of hidden rows; B*N*2C keeps room for the SD3 K | V packs)
  *   univst_comm_export(c, handle)                      univst_comm_handle_bytes() bytes, to be all-gathered out of band
  *   univst_comm_connect(c, all_handles)                rank-major array of every rank's handle
  *   univst_unet_set_comm_native(unet, c)               the UNet graph now uses it instead of callbacks
