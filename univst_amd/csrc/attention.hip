@@ -1793,8 +1793,10 @@ int uv_launch_attention(const AttnParams& p0, hipStream_t stream) {
     const double nkv = (double)p.nsrc * p.Nkv;
     const int cls = (p.nsrc == 1 && p.Nkv <= 128) ? UV_CLS_ATTN_TEXT
                     : (p.d == 40 && p.Nq >= 2048) ? UV_CLS_ATTN_D40 : (p.d == 80 ? UV_CLS_ATTN_D80 : UV_CLS_ATTN_OTHER);
-    uv_prof_begin(cls, 4.0 * p.BF * p.heads * (double)p.Nq * nkv * p.d,
-                  2.0 * p.BF * p.heads * p.d * (2.0 * p.Nq + 2.0 * nkv), stream);
+    // (a two-phase attention is ONE algorithmic attention over the reference's key set: the first phase is charged its flops, the merge phase none —
+    // the host does not know how the sources split between the two)
+    uv_prof_begin(cls, p.state_in ? 0.0 : 4.0 * p.BF * p.heads * (double)p.Nq * nkv * p.d,
+                  2.0 * p.BF * p.heads * p.d * (2.0 * p.Nq + (p.state_in ? 0.0 : 2.0 * nkv)), stream);
     int rc = attn_dispatch(p, stream);
     uv_prof_end(stream);
     return rc;
