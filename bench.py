@@ -53,6 +53,10 @@ def parse():
                     help="with --emulate-rank: model the wire too — every K/V exchange keeps the stream busy for pack bytes / GBPS (per-direction rate of one "
                          "xGMI link; rank 1's link from rank 0 carries two packs) and every GroupNorm all-reduce for LAT_US (default 3); serial, as csrc/comm.hip "
                          "issues them today")
+    ap.add_argument("--comm-emulated", action="store_true",
+                    help="with --emulate-rank and --emulate-wire: drive the rank through the library's OWN communicator in its emulated mode "
+                         "(univst_comm_connect_emulated: production kernels, forked stream and flag waits, transfers replaced by delays) instead of "
+                         "host callbacks that return at once; required for ranks > 0 of --workload sd3_transfer")
     ap.add_argument("--emulate-rank", default=None, metavar="R/W",
                     help="diagnostic: run the work of rank R of a W-GPU job alone on this GPU with no-op collectives (kernels, pack/unpack "
                          "and host callbacks of a frame shard, no wire time); prints the usual line with parallelism 'emulated R/W'")
@@ -345,11 +349,19 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
         # one rank of a w-GPU job alone, no wire: its F/w frames of every branch as whole clips of that length — the same kernels and key
         # counts ([first | previous | current] + text) as the sharded rank runs, minus the K | V pack copies and the exchange
         er, ew = (int(v) for v in a.emulate_rank.split("/"))
-        # exact for rank 0 only: its 'first' and 'previous' frames are local.  A rank r > 0 reads both from halo blocks, so each of its frames
-        # has three DISTINCT key sources (rank 0 with two frames: one and two after merging duplicates) — that needs the communicator's inboxes
-        assert er == 0, "--workload sd3_transfer --emulate-rank: only rank 0 can be emulated without a communicator (ranks > 0 need the halo blocks)"
         emu = (er, ew)
-        shard = Sd3FrameShard(0, 1, F_all // ew)
+        if a.comm_emulated:
+            # any rank, through the library's communicator in emulated mode: the real sharded op (pack, post on the forked stream, two-phase joint
+            # attention, flag wait, unpack, barrier) with the transfers replaced by delays of pack bytes / link rate
+            from univst_amd.parallel import EmulatedIpcComm
+            assert a.emulate_wire, "--comm-emulated needs --emulate-wire GBPS[,LAT_US]"
+            wire = [float(v) for v in a.emulate_wire.split(",")]
+            shard = Sd3FrameShard(er, ew, F_all, comm=EmulatedIpcComm(er, ew, 1 << 17, *wire))
+        else:
+            # exact for rank 0 only: its 'first' and 'previous' frames are local.  A rank r > 0 reads both from halo blocks, so each of its frames
+            # has three DISTINCT key sources (rank 0 with two frames: one and two after merging duplicates) — that needs the communicator's inboxes
+            assert er == 0, "--workload sd3_transfer --emulate-rank: only rank 0 can be emulated without a communicator (ranks > 0: --comm-emulated)"
+            shard = Sd3FrameShard(0, 1, F_all // ew)
     else:
         shard = Sd3FrameShard(rank, world, F_all)
     F_ = shard.local
@@ -359,7 +371,7 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
     model = model.half().requires_grad_(False)
     pipe = CustomStableDiffusion3Pipeline(transformer=model, scheduler=FlowMatchEulerDiscreteScheduler())
     pnp_utils.register_spatial_attention_pnp(pipe)
-    if emu is not None:
+    if emu is not None and not a.comm_emulated:
         for proc in model.attn_processors.values():
             proc.clip_length = F_
     shard.attach(model, tokens=(hl // 2) ** 2)
@@ -394,11 +406,14 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
     for i in range(max(1, a.warmup)):
         lat = step(idx[i % len(idx)], lat)
     sync()
+    if emu is not None and a.comm_emulated:
+        shard.comm.wire_us()                   # (reading resets the counter)
     t0 = time.perf_counter()
     for i in idx:
         lat = step(i, lat)
     sync()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    sd3_wire_ms = (shard.comm.wire_us() / a.steps / 1e3) if (emu is not None and a.comm_emulated) else None
     if dist is not None:                      # MAX over ranks
         outs = [None] * world
         dist.all_gather_object(outs, ms)
@@ -412,8 +427,11 @@ def run_sd3_workload(a, dev, rank=0, world=1, dist=None):
            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": max(1, a.warmup), "ms_per_step": round(ms, 2), "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic latents + prompt embeddings, random-init weights (2.2 B parameters)",
            "config": {"workload": f"sd35_medium_mmdit_three_branch_transfer_{F_}x{hl * 8}x{hl * 8}_50rf", "frames": F_, "tokens_per_frame": N,
-                      "text_tokens": T, "batch": 3 * F_, "parallelism": (f"rank {emu[0]} of {emu[1]} emulated (no wire): {F_all // emu[1]} frames per branch" if emu else
+                      "text_tokens": T, "batch": 3 * F_, "parallelism": ((f"rank {emu[0]} of {emu[1]} emulated through the library's communicator (wire modelled at {a.emulate_wire} GB/s per link, "
+                                                                           f"{'exchange on the forked stream' if os.environ.get('UNIVST_KV_OVERLAP', '1') != '0' else 'serial'}): {F_all // emu[1]} frames per branch"
+                                                                           if a.comm_emulated else f"rank {emu[0]} of {emu[1]} emulated (no wire): {F_all // emu[1]} frames per branch") if emu else
                                                                           "single" if world == 1 else f"frames{world} (IPC communicator)"),
+                      **({"modelled_wire_ms_per_step": round(sd3_wire_ms, 3)} if sd3_wire_ms is not None else {}),
                       "note": "BASELINE config 5 names 8 GPUs and fp8 QKV; fp16 here (the reference's --weight_dtype default); --gpus N shards the frames"}}
     tf = fl / (ms * 1e-3) / 1e12 / (emu[1] if emu else world)
     out["roofline"] = {"bound": "mfma", "kernel": "whole step (linears + joint attention), per GPU", "achieved": round(tf, 1), "peak": PEAK_FP16_TFLOPS,
@@ -529,7 +547,12 @@ def main():
         er, ew = (int(v) for v in a.emulate_rank.split("/"))
         emu = (er, ew)
         wire = [float(v) for v in a.emulate_wire.split(",")] if a.emulate_wire else None
-        shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew, *(wire or []), kv_in_library=True))
+        if a.comm_emulated:
+            from univst_amd.parallel import EmulatedIpcComm
+            assert wire, "--comm-emulated needs --emulate-wire GBPS[,LAT_US]"
+            shard = FrameShard(er, ew, F_total, comm=EmulatedIpcComm(er, ew, 1 << 17, *wire))
+        else:
+            shard = FrameShard(er, ew, F_total, comm=NullComm(er, ew, *(wire or []), kv_in_library=True))
     else:
         shard = FrameShard(rank, world, F_total)
     unet = synth.build_unet(config=synth.SD21_UNET_CONFIG if a.model == "sd21" else None, device=dev, seed=33)
@@ -547,7 +570,7 @@ def main():
         mask_m = _native.mask_resize(mask.reshape(-1, 8 * h, 8 * h).contiguous(), h, h)
         mask_m = mask_m.reshape(-1, h, h)[shard.f0:shard.f0 + shard.local].contiguous()
     shard.attach(unet, max_tokens=h * h)
-    if emu is not None and a.emulate_wire:
+    if emu is not None and a.emulate_wire and not a.comm_emulated:
         # the K/V exchanges' wire time is modelled INSIDE the library, on the forked stream the real multicast runs on (csrc/unet.hip Fwd::kv_post), so the
         # emulation shows what the overlap hides; the GroupNorm all-reduces' flag round trips stay in NullComm on the forward's stream
         unet.set_native_option("emu_wire_gbps", int(wire[0]))
@@ -594,7 +617,9 @@ def main():
     for i in range(a.warmup):
         lat = step(i % 50, lat)
     sync()
-    if emu is not None:
+    if emu is not None and a.comm_emulated:
+        shard.comm.wire_us()
+    elif emu is not None:
         shard.comm.wire_us = 0.0
         _native.unet_query(unet._native_handle, "emu_wire_us")
     t0 = time.perf_counter()
@@ -602,7 +627,10 @@ def main():
         lat = step(i, lat)
     sync()
     dt = time.perf_counter() - t0
-    wire_ms_per_step = ((shard.comm.wire_us + _native.unet_query(unet._native_handle, "emu_wire_us")) / a.steps / 1e3) if emu is not None and a.emulate_wire else None
+    if emu is not None and a.comm_emulated:
+        wire_ms_per_step = shard.comm.wire_us() / a.steps / 1e3
+    else:
+        wire_ms_per_step = ((shard.comm.wire_us + _native.unet_query(unet._native_handle, "emu_wire_us")) / a.steps / 1e3) if emu is not None and a.emulate_wire else None
     kv_overlap = os.environ.get("UNIVST_KV_OVERLAP", "1") != "0"
     if dist is not None:
         tmax = torch.tensor([dt], device=dev if a.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -622,7 +650,7 @@ def main():
                                 f"{a.model}_unet_three_branch_pnp_transfer_{F_total}x{h * 8}x{h * 8}_50ddim"), "frames": F_total,
                    "latent": [1, 4, F_total, h, h], "branches": (2 if pair else 1) if inv else 3,
                    "schedule_steps": "all 50" if a.steps == 50 else (f"{a.steps} of 50, evenly spread" if a.steps < 50 else f"{a.steps} (wrapping modulo 50)"),
-                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} ({'wire modelled at ' + a.emulate_wire + ' GB/s per link, ' + ('K/V exchange on the forked stream' if kv_overlap else 'serial') if a.emulate_wire else 'no wire'})" if emu else "single") if world == 1 else f"frames{world}",
+                   "masks": "moving disc, blended on steps 0..45" if masked else None, "parallelism": (f"emulated rank {emu[0]}/{emu[1]} ({'wire modelled at ' + a.emulate_wire + ' GB/s per link, ' + ('K/V exchange on the forked stream' if kv_overlap else 'serial') + (', through the library communicator in emulated mode' if a.comm_emulated else '') if a.emulate_wire else 'no wire'})" if emu else "single") if world == 1 else f"frames{world}",
                    "comm": None if world == 1 else type(shard.comm).__name__, "shard_check": shard_check,
                    **({"modelled_wire_ms_per_step": round(wire_ms_per_step, 3)} if wire_ms_per_step is not None else {}),
                    "weights": ("random-init SD-v2.1 layout (Linear projections, head_dim 64, text width 1024), fp16" if a.model == "sd21" else

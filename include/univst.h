@@ -111,6 +111,12 @@ int univst_comm_export(univst_comm* c, void* handle_out);
 int univst_comm_connect(univst_comm* c, const void* handles);
 /* ranks that are host threads of ONE process (tests on a 1-GPU box): `all` = the `world` communicators in rank order */
 int univst_comm_connect_local(univst_comm* c, univst_comm* const* all);
+/* ONE rank of a `world`-rank job alone on one GPU (bench.py --emulate-rank r/w --comm-emulated; measurement aid, results are meaningless): every peer
+ * is this rank's own region; an exchange's post becomes a delay of latency + (packs on this rank's busiest link) x bytes / link rate followed by a
+ * raise of its own inbox flags, on the stream the multicast would run on; an all-reduce runs over this rank alone after `latency_us`.  Kernels, streams
+ * and flag waits are the production ones.  univst_comm_query("emu_wire_us"): the modelled time issued since the last query. */
+int univst_comm_connect_emulated(univst_comm* c, double link_gbps, double latency_us);
+int univst_comm_query(univst_comm* c, const char* name, double* out);
 int univst_comm_destroy(univst_comm* c);
 /* in-place SUM over ranks of n <= 1024 fp32 in device memory, identical bits on every rank (slots summed in rank order) */
 int univst_comm_allreduce_f32(univst_comm* c, void* buf, int n, void* stream);

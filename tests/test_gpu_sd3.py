@@ -691,6 +691,30 @@ def test_bench_sd3_two_ranks_end_to_end():
 # registered.  Frames reduced to 3 branches x 3 so the fp32 oracle fits on the device next to the model (2.2 B parameters twice): the
 # geometry per frame — ragged 256 x 320 tiles of the 1536 / 4608 / 6144-wide linears, attn_pp64_kernel over 3 x 4096 + 333 keys,
 # merged duplicate sources at f = 0, 1 — is config 5's.
+@pytest.mark.parametrize("rank,world", [(1, 8), (0, 8), (7, 8)])
+def test_sd3_emulated_communicator_rank(nat, rank, world):
+    """the sharded joint attention of one rank ALONE through the communicator's emulated mode (bench.py --workload sd3_transfer --emulate-rank r/8
+    --emulate-wire G --comm-emulated): pack, post on the forked stream, two-phase joint attention on ranks > 0, flag wait, unpack, barrier — finite
+    output, no bounded wait gave up, wire time accounted (one exchange + one barrier per attention call)."""
+    from univst_amd import _native
+    from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
+    from univst_amd.parallel import Sd3FrameShard, EmulatedIpcComm
+    m, _ = _tiny_sd3(layers=2, dual=(0,))
+    pnp_utils.register_spatial_attention_pnp(types.SimpleNamespace(transformer=m), eta1=0.0, eta2=0.6)
+    lat, enc, pooled, t = _sd3_inputs(48, 8, 5, seed=9)
+    comm = EmulatedIpcComm(rank, world, 1 << 17, wire_gbps=50.0, latency_us=2.0)
+    sh = Sd3FrameShard(rank, world, 16, comm=comm).attach(m, tokens=16)
+    comm.wire_us()
+    for idx in (10, 45):
+        v = m(hidden_states=sh.slice_branches(lat).cuda(), timestep=t.cuda().expand(3 * sh.local), encoder_hidden_states=sh.slice_branches(enc).cuda(),
+              pooled_projections=sh.slice_branches(pooled).cuda(), return_dict=False, joint_attention_kwargs={"idx": idx})[0]
+        torch.cuda.synchronize()
+        assert torch.isfinite(v.float()).all()
+    assert _native.load().univst_comm_status(comm.ptr) == 0
+    assert comm.wire_us() >= 2 * 3 * (2.0 + 2.0)          # 2 forwards x 3 attention calls (2 layers, one dual) x (exchange + barrier) x latency
+    comm.close()
+
+
 def _sd35_medium_for_tests():
     from univst_amd.backbones.video_diffusion_sd3 import pnp_utils
     from univst_amd.backbones.video_diffusion_sd3.models.transformer_3D_model import sd35_medium

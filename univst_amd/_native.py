@@ -65,6 +65,8 @@ SIGNATURES = {
     "univst_comm_export": (_I, [_P, _P]),
     "univst_comm_connect": (_I, [_P, _P]),
     "univst_comm_connect_local": (_I, [_P, C.POINTER(_P)]),
+    "univst_comm_connect_emulated": (_I, [_P, C.c_double, C.c_double]),
+    "univst_comm_query": (_I, [_P, C.c_char_p, C.POINTER(C.c_double)]),
     "univst_comm_destroy": (_I, [_P]),
     "univst_comm_allreduce_f32": (_I, [_P, _P, _I, _P]),
     "univst_comm_status": (_I, [_P]),

@@ -27,6 +27,8 @@
 #include "kernels.h"
 #include "unet.h"
 
+int uv_launch_delay_us(double us, hipStream_t s);
+
 namespace {
 
 constexpr int UV_COMM_MAXW = 8;
@@ -123,6 +125,12 @@ struct univst_comm {
     unsigned ar_epoch = 0, kv_epoch = 0;
     int* status = nullptr;                                   // host-mapped: 0 ok, 100 + r / 200 + k = gave up waiting
     hipStream_t stream = nullptr;                            // the stream of the forward() in flight (callbacks carry none)
+    // EMULATED rank (bench.py --emulate-rank r/w --comm-emulated; univst_comm_connect_emulated): rank r of a `world`-rank job ALONE on one GPU — every
+    // peer pointer is this rank's own region, a post is a delay kernel of latency + (packs on this rank's busiest link) x bytes / rate followed by a raise
+    // of this rank's OWN inbox flags, an all-reduce runs over this rank alone after one flag round trip of delay.  The kernels, streams and flag waits
+    // are the production ones; the payload is whatever the inbox holds (zeros): timing only.
+    bool emulated = false;
+    double emu_gbps = 0.0, emu_lat_us = 0.0, emu_wire_us = 0.0;
     hipStream_t xstream = nullptr;                           // forked stream of callers without one of their own (the SD3 joint attention: uv_comm_fork)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -143,6 +151,16 @@ int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s) {
     if (rc) return rc;
     Peers pe;
     for (int i = 0; i < UV_COMM_MAXW; ++i) pe.p[i] = c->peer[i];
+    if (c->emulated) {              // one flag round trip, then the kernel over this rank alone (as rank 0 of a world of 1 on its own region)
+        if (c->emu_lat_us > 0.0) {
+            int drc = uv_launch_delay_us(c->emu_lat_us, s);
+            if (drc) return drc;
+            c->emu_wire_us += c->emu_lat_us;
+        }
+        hipLaunchKernelGGL(comm_allreduce_kernel, dim3(1), dim3(256), 0, s, pe, 0, 1, ++c->ar_epoch, buf, n, c->status);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
     hipLaunchKernelGGL(comm_allreduce_kernel, dim3(1), dim3(256), 0, s, pe, c->rank, c->world, ++c->ar_epoch, buf, n, c->status);
     UV_LAUNCH_CHECK();
     return UV_OK;
@@ -167,6 +185,21 @@ static int comm_kv_post(univst_comm* c, int64_t o_send, int64_t o_first, int64_t
     const unsigned epoch = ++c->kv_epoch;
     const int par = epoch & 1;
     auto flag = [&](int r, int which) { return reinterpret_cast<unsigned*>(c->peer[r] + UV_OFF_FLAGS) + 32 + par * 2 + which; };
+    if (c->emulated) {
+        // the slowest transfer this rank waits for: one pack per link (the first-frame pack from rank 0, the halo pack from rank - 1), except on rank 1
+        // whose one link from rank 0 carries both; rank 0 only sends (its outgoing links carry one pack each)
+        const double us = c->emu_lat_us + (c->rank == 1 ? 2.0 : 1.0) * (double)nbytes / (c->emu_gbps * 1e3);
+        c->emu_wire_us += us;
+        rc = uv_launch_delay_us(us, x);
+        if (rc) return rc;
+        Flags fe;
+        fe.n = 2;
+        fe.f[0] = flag(c->rank, 0);
+        fe.f[1] = flag(c->rank, 1);
+        hipLaunchKernelGGL(comm_raise_kernel, dim3(1), dim3(64), 0, x, fe, epoch);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
     const long nvec = nbytes / 16;
     const unsigned grid = (unsigned)((nvec + 256 * 8 - 1) / (256 * 8) < 1024 ? (nvec + 256 * 8 - 1) / (256 * 8) : 1024);
     Flags fl;
@@ -271,6 +304,28 @@ int univst_comm_connect_local(univst_comm* c, univst_comm* const* all) {
     }
     c->connected = true;
     return UV_OK;
+}
+
+// bench.py --comm-emulated: this rank alone stands for rank `c->rank` of `c->world` (see struct univst_comm::emulated)
+int univst_comm_connect_emulated(univst_comm* c, double link_gbps, double latency_us) {
+    UV_REQUIRE(c, "comm_connect_emulated: null argument");
+    UV_REQUIRE(link_gbps > 0.0 && latency_us >= 0.0 && latency_us < 1e5, "comm_connect_emulated: link rate %f GB/s, latency %f us", link_gbps, latency_us);
+    for (int r = 0; r < c->world; ++r) c->peer[r] = c->mine;
+    c->emulated = true;
+    c->emu_gbps = link_gbps;
+    c->emu_lat_us = latency_us;
+    c->connected = true;
+    return UV_OK;
+}
+int univst_comm_query(univst_comm* c, const char* name, double* out) {
+    UV_REQUIRE(c && name && out, "comm_query: null argument");
+    if (!strcmp(name, "emu_wire_us")) {          // modelled wire time issued since the last query (reading resets it)
+        *out = c->emu_wire_us;
+        c->emu_wire_us = 0.0;
+        return UV_OK;
+    }
+    uv_set_error("comm_query: unknown quantity '%s'", name);
+    return UV_ERR_ARG;
 }
 
 int univst_comm_destroy(univst_comm* c) {

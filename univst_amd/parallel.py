@@ -151,7 +151,7 @@ class FrameShard:
         if handle is self._handle and tokens <= self._tokens:
             return
         tokens = max(tokens, self._tokens)
-        if isinstance(self.comm, NativeIpcComm):     # the communicator owns the (IPC-shared) workspace; no callbacks
+        if isinstance(self.comm, (NativeIpcComm, EmulatedIpcComm)):     # the communicator owns the (IPC-shared) workspace; no callbacks
             self.comm.ensure_bytes(self._ws_bytes(unet, tokens))
             _native.check(_native.load().univst_unet_set_comm_native(handle, self.comm.ptr), "unet_set_comm_native")
             self._tokens, self._handle = tokens, handle
@@ -511,6 +511,58 @@ class NativeIpcComm:
         try:
             if self.ptr is not None:
                 _native.load().univst_comm_destroy(self.ptr)
+        except Exception:
+            pass
+
+
+class EmulatedIpcComm:
+    """ONE rank of a `world`-rank job alone on one GPU, through the library's communicator in its emulated mode (``univst_comm_connect_emulated``):
+    the production kernels, forked stream and flag waits, with every transfer replaced by a delay of latency + packs-on-the-busiest-link x bytes / rate.
+    ``bench.py --emulate-rank r/w --emulate-wire GBPS --comm-emulated``; results are meaningless, only the timing is used."""
+
+    def __init__(self, rank: int, world: int, ws_bytes: int, wire_gbps: float, latency_us: float = 3.0, device=None):
+        self.rank, self.world = rank, world
+        self.wire_gbps, self.latency_us = float(wire_gbps), float(latency_us)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.ptr, self.ws_bytes = None, 0
+        self._build(ws_bytes)
+
+    def _build(self, ws_bytes: int):
+        lib = _native.load()
+        if self.ptr is not None:
+            torch.cuda.synchronize()
+            lib.univst_comm_destroy(self.ptr)
+            self.ptr = None
+        h = C.c_void_p()
+        _native.check(lib.univst_comm_create(self.rank, self.world, int(ws_bytes), C.byref(h)), "comm_create")
+        _native.check(lib.univst_comm_connect_emulated(h, self.wire_gbps, self.latency_us), "comm_connect_emulated")
+        self.ptr, self.ws_bytes = h, int(ws_bytes)
+
+    def ensure_bytes(self, ws_bytes: int):
+        if ws_bytes > self.ws_bytes:
+            self._build(ws_bytes)
+
+    def all_reduce_sum(self, t: torch.Tensor):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _native.check(_native.load().univst_comm_allreduce_f32(self.ptr, t.data_ptr(), t.numel(), _native.stream_ptr()), "comm_allreduce")
+
+    def all_gather(self, t):
+        return [t for _ in range(self.world)]
+
+    def wire_us(self) -> float:
+        out = C.c_double(0.0)
+        _native.check(_native.load().univst_comm_query(self.ptr, b"emu_wire_us", C.byref(out)), "comm_query")
+        return out.value
+
+    def close(self):
+        if self.ptr is not None:
+            torch.cuda.synchronize()
+            _native.load().univst_comm_destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass
 
