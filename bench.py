@@ -239,7 +239,7 @@ def run_vae_workload(a, dev):
             "config": {"workload": f"svd_temporal_vae_decode_{F_}x{h * 8}x{h * 8}", "frames": F_, "parallelism": "single",
                        "weights": "random-init AutoencoderKLTemporalDecoder architecture (128, 256, 512, 512), fp16",
                        "algorithmic_tflop_per_decode": round(fl / 1e12, 2)},
-            "roofline": {"kernel": "gemm_kernel<4,1> (128 x 128 implicit-GEMM conv tile: the VAE widths 128 / 256 / 512 are not multiples of the 320-column tile)",
+            "roofline": {"kernel": "gemm_kernel<4,1> (128 x 128 implicit-GEMM conv tile: the 128-wide convs of the 512 x 512 level, 44 % of the decode's kernel time; the 256 / 512-wide convs run on the ragged 256 x 320 tile, 34 %; GroupNorm passes 18 % — rocprofv3 trace of round 6)",
                          "bound": "mfma", "achieved": round(fl / (dev_ms * 1e-3) / 1e12, 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(fl / (dev_ms * 1e-3) / 1e12 / PEAK_FP16_TFLOPS, 4), "traffic": None,
                          "note": "whole-decode figure (all launches of one decode); off the 50-step loop: the metric's timed region ends before the final decode"}}

@@ -383,7 +383,7 @@ int uv_comm_kv_wait(univst_comm* c, hipStream_t s) {
     UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
     return comm_kv_wait(c, s);
 }
-// a forked stream for callers that have none (csrc/sd3.hip): *x runs after everything queued on s so far; uv_comm_join makes s wait for what x holds
+// a forked stream for callers that have none (csrc/sd3.hip): *x runs after everything queued on s so far; uv_comm_join makes s wait for what x holds (unused since the layer's barrier retires the fork: a cross-queue event into s cost 30x in the 2-process tests; kept for callers without a barrier)
 int uv_comm_fork(univst_comm* c, hipStream_t s, hipStream_t* x) {
     static const int ov = getenv("UNIVST_KV_OVERLAP") ? atoi(getenv("UNIVST_KV_OVERLAP")) : 1;
     if (!ov) {
