@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv
 // that occurs c times is listed once with log2-weight log2(c) — softmax over duplicated keys == softmax with the key's exp weighted c.
 // clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): the frame itself, once.
 // Frame shard (world > 1): this rank holds frames [rank*clip, (rank+1)*clip) of every branch; the clip's first frame and the frame
-// before this rank's first one arrive in the row blocks B + 2b (first) and B + 2b + 1 (previous) of branch b.
+// before this rank's first one are projected from the received hidden rows into the row blocks B + b (first) and B + nbr + b (previous) of branch b.
 // phase (round 6, ranks > 0 of a frame shard: the two-phase attention of csrc/attention.hip): 0 = the whole key set; 1 = only the sources this rank
 // HOLDS (the frame itself and, from its second local frame on, the previous one); 2 = only the halo sources (the clip's first frame and, for the rank's
 // first local frame, the frame before it — merged into one source of weight 2 where they are the same frame).
@@ -171,8 +171,9 @@ __global__ void sd3_index_kernel(int B, int clip, int rank, int* __restrict__ sr
     }
     const int b = bf / clip, f = bf - b * clip;
     const int gf = rank * clip + f;                                   // frame index in the whole clip
-    const int first = rank == 0 ? b * clip : B + 2 * b;               // row block holding the clip's first frame
-    const int prev = f > 0 ? bf - 1 : B + 2 * b + 1;                  // (gf >= 1) row block of frame gf - 1
+    const int nbr = B / clip;
+    const int first = rank == 0 ? b * clip : B + b;                   // row block holding the clip's first frame (halo blocks: [first: nbr | previous: nbr])
+    const int prev = f > 0 ? bf - 1 : B + nbr + b;                    // (gf >= 1) row block of frame gf - 1
     if (phase == 1) {                       // rank > 0: gf >= 1
         cnt[bf] = f > 0 ? 2 : 1;
         if (f > 0) si[0] = prev;            // [prev, cur] / [cur]
@@ -477,7 +478,8 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
     // one stream-ordered scratch block: qkv_img [rows_i, 3C] | qkv_txt [rows_t, 3C] | o_img [rows_i, C] | o_txt [rows_t, C] | stats | index tables
     const int Fb = B / 3;                                    // frames per branch (shift only)
     const size_t n_half = (size_t)(rows_i + rows_t) * 4 * C + (size_t)rows_x * 3 * C;
-    const size_t n_stat = shift ? (size_t)4 * Fb * 2 * C + (size_t)2 * Fb * 2 * heads : 0;
+    const int Fst = Fb > 1 ? Fb : 1;
+    const size_t n_stat = shift ? (size_t)4 * Fst * 2 * C + (size_t)2 * Fst * 2 * heads : 0;
     char* ws = nullptr;
     const bool two_phase = sharded && rank > 0;              // round 6: the keys this rank holds first, the halo frames continue from the softmax state
     const size_t n_state = two_phase ? (size_t)(rows_i + rows_t) * heads * 2 : 0;
@@ -504,6 +506,37 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             const bool bf = (!qb && !kb && !vb) || (qb && H(kb) == H(qb) + C && H(vb) == H(kb) + C);
             return wf && bf;
         };
+        // ---- frame shard, first half of the exchange (round 6), before anything else of the layer: the HIDDEN rows (this op's input: the adaLN-modulated
+        // tokens every projection reads) of this rank's last frame of every branch -> rank + 1, of the clip's first frame (rank 0) -> every rank, on the
+        // communicator's forked stream.  Pack [branch][N][Cin] — half the K | V pack of rounds 3-5 — in the communicator's workspace: 64 KiB of
+        // all-reduce scratch, then send | first | inbox[parity][previous, first].  The RECEIVER projects the two halo frames to K | V, applies the k
+        // RMSNorm and (inside the window) the AdaIN shift itself: all per frame (pnp_utils.py:183-194).  The transfer runs beside this rank's own
+        // projections and the attention over the keys it holds.
+        long o_prev = 0, o_rfirst = 0;
+        char* ws_c = sharded ? uv_comm_ws(comm) : nullptr;
+        hipStream_t xs = s;
+        if (sharded) {
+            const long pack = (((long)nbr * N * Cin * (long)sizeof(half_t)) + 255) & ~255L;
+            UV_REQUIRE(65536 + 6 * pack <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
+                       "6 hidden-row packs of %ld bytes", uv_comm_ws_bytes(comm), pack);
+            const long o_send = 65536, o_first = 65536 + pack;
+            const unsigned par = uv_comm_kv_parity(comm);
+            o_prev = 65536 + (2 + 2 * par) * pack;
+            o_rfirst = o_prev + pack;
+            const long cpn = (long)N * (Cin / 8);
+            const unsigned cgrid = (unsigned)((cpn + 255) / 256);
+            for (int b = 0; b < nbr; ++b) {
+                if (rank < world - 1)
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, x + ((long)(b * clip_length + clip_length - 1) * N) * Cin, (long)Cin,
+                                       (half_t*)(ws_c + o_send) + (long)b * N * Cin, (long)Cin, (long)N, Cin / 8);
+                if (rank == 0)
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, x + ((long)b * clip_length * N) * Cin, (long)Cin,
+                                       (half_t*)(ws_c + o_first) + (long)b * N * Cin, (long)Cin, (long)N, Cin / 8);
+            }
+            UV_LAUNCH_CHECK();
+            if (rank < world - 1) RUN(uv_comm_fork(comm, s, &xs));       // (the last rank posts nothing)
+            RUN(uv_comm_kv_post(comm, o_send, o_first, o_prev, o_rfirst, (long)nbr * N * Cin * (long)sizeof(half_t), xs));
+        }
         if (fused3(w->to_q, w->to_k, w->to_v, w->to_q_bias, w->to_k_bias, w->to_v_bias)) {
             RUN(linear(x, Cin, rows_i, Cin, H(w->to_q), H(w->to_q_bias), 3 * C, qkv_i, 3 * C, s));
         } else {
@@ -520,36 +553,6 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         else if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
         if (shift) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0); window test + beta come from the caller, evaluated in double
             RUN(univst_sd3_adain_shift(qkv_i, 3 * C, Fb, N, C, heads, 0.8f, beta, 2.0f, st, s));
-        }
-        // ---- frame shard, first half of the exchange (round 6: BEFORE the text stream's projections, on the communicator's forked stream): K | V of this
-        // rank's last frame of every branch -> rank + 1, of the clip's first frame (rank 0) -> every rank; after the AdaIN shift, which rewrites the
-        // stylised branch's K / V.  Pack [branch][N][2C] in the communicator's workspace: 64 KiB of all-reduce scratch, then send | first |
-        // inbox[parity][previous, first].  The transfer then runs beside the text projections and the attention over the keys this rank holds.
-        long o_prev = 0, o_rfirst = 0;
-        const long cpn = (long)N * (2 * C / 8);
-        const unsigned cgrid = (unsigned)((cpn + 255) / 256);
-        char* ws_c = sharded ? uv_comm_ws(comm) : nullptr;
-        hipStream_t xs = s;
-        if (sharded) {
-            const long pack = (((long)nbr * N * 2 * C * (long)sizeof(half_t)) + 255) & ~255L;
-            UV_REQUIRE(65536 + 6 * pack <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
-                       "6 K/V packs of %ld bytes", uv_comm_ws_bytes(comm), pack);
-            const long o_send = 65536, o_first = 65536 + pack;
-            const unsigned par = uv_comm_kv_parity(comm);
-            o_prev = 65536 + (2 + 2 * par) * pack;
-            o_rfirst = o_prev + pack;
-            for (int b = 0; b < nbr; ++b) {
-                const half_t* last = qkv_i + ((long)(b * clip_length + clip_length - 1) * N) * 3 * C + C;
-                if (rank < world - 1)
-                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, last, (long)3 * C, (half_t*)(ws_c + o_send) + (long)b * N * 2 * C,
-                                       (long)2 * C, (long)N, 2 * C / 8);
-                if (rank == 0)
-                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, qkv_i + ((long)b * clip_length * N) * 3 * C + C, (long)3 * C,
-                                       (half_t*)(ws_c + o_first) + (long)b * N * 2 * C, (long)2 * C, (long)N, 2 * C / 8);
-            }
-            UV_LAUNCH_CHECK();
-            if (rank < world - 1) RUN(uv_comm_fork(comm, s, &xs));       // (the last rank posts nothing)
-            RUN(uv_comm_kv_post(comm, o_send, o_first, o_prev, o_rfirst, (long)nbr * N * 2 * C * (long)sizeof(half_t), xs));
         }
         if (enc) {
             const half_t* e = H(enc);
@@ -598,12 +601,25 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             UV_LAUNCH_CHECK();
             RUN(attend(1));                                                  // the keys this rank holds ++ the text keys, while the halo is on the wire
             RUN(uv_comm_kv_wait(comm, s));
-            for (int b = 0; b < nbr; ++b) {
-                half_t* xf = qkv_i + (rows_i + (long)(2 * b) * N) * 3 * C + C;
-                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_rfirst) + (long)b * N * 2 * C, (long)2 * C,
-                                   xf, (long)3 * C, (long)N, 2 * C / 8);
-                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, (const half_t*)(ws_c + o_prev) + (long)b * N * 2 * C, (long)2 * C,
-                                   xf + (long)N * 3 * C, (long)3 * C, (long)N, 2 * C / 8);
+            // the two halo frames of every branch from their hidden rows: to_k | to_v (+ biases) -> k RMSNorm -> the shift of each frame; rows behind the
+            // local ones, [first: nbr x N | previous: nbr x N]
+            half_t* qh = qkv_i + rows_i * 3 * C;
+            const long hrows = (long)nbr * N;
+            const bool kvf = H(w->to_v) == H(w->to_k) + (long)C * Cin && ((!w->to_k_bias && !w->to_v_bias) || (w->to_k_bias && H(w->to_v_bias) == H(w->to_k_bias) + C));
+            for (int sl = 0; sl < 2; ++sl) {
+                const half_t* hx = (const half_t*)(ws_c + (sl == 0 ? o_rfirst : o_prev));
+                half_t* dst = qh + (long)sl * hrows * 3 * C;
+                if (kvf) {
+                    RUN(linear(hx, Cin, hrows, Cin, H(w->to_k), H(w->to_k_bias), 2 * C, dst + C, 3 * C, s));
+                } else {
+                    RUN(linear(hx, Cin, hrows, Cin, H(w->to_k), H(w->to_k_bias), C, dst + C, 3 * C, s));
+                    RUN(linear(hx, Cin, hrows, Cin, H(w->to_v), H(w->to_v_bias), C, dst + 2 * C, 3 * C, s));
+                }
+            }
+            if (w->norm_k) RUN(univst_rmsnorm_heads(qh + C, 3 * C, 2 * hrows, heads, head_dim, w->norm_k, rms_eps, s));
+            if (shift) {          // a halo frame of the three branches is the shift kernel's [3][F = 1][N]; its q columns are never projected and never read (the
+                                  // kernel mixes them element-wise, statistics come from k / v only)
+                for (int sl = 0; sl < 2; ++sl) RUN(univst_sd3_adain_shift(qh + (long)sl * hrows * 3 * C, 3 * C, 1, N, C, heads, 0.8f, beta, 2.0f, st, s));
             }
             index(2);
             UV_LAUNCH_CHECK();
