@@ -318,7 +318,8 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
                                univst_comm* comm /* may be NULL */, void* stream);
 /* comm (frame shard, world > 1): the batch holds frames [rank*clip_length, (rank+1)*clip_length) of every branch; K | V of the clip's
  * first frame (from rank 0) and of the frame before this rank's first one (from rank - 1) arrive through the communicator's peer
- * writes (one exchange + one one-float all-reduce as a barrier per call; workspace >= 64 KiB + 6 x branches*N*2C fp16). */
+ * writes (one exchange + one one-float all-reduce as a barrier per call; workspace >= 64 KiB + 6 x branches*N*Cin fp16: since round 6 a pack is the layer's HIDDEN rows of a boundary frame, posted on the communicator's forked
+ * stream at the start of the op; the receiving rank projects them to K | V, applies the k RMSNorm and the shift, and attends in two phases). */
 /* the shift alone, in place on a fused [3*F*N, 3C] q | k | v buffer (branch 0 content, 1 style, 2 stylised; row stride ld):
  * q2 <- gamma*(alpha*q0 + (1-alpha)*q2);  k2 <- beta*AdaIN(k2; k1) + (1-beta)*k1 (same for v) with the SD3 plugin's AdaIN
  * (pnp_utils.py:289-302: F.instance_norm over (N, head_dim) jointly per (frame, head), style mean / unbiased std per channel over N).
