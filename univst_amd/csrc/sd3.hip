@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void sd3_shift_kernel(half_t* __restrict__ qkv
 // that occurs c times is listed once with log2-weight log2(c) — softmax over duplicated keys == softmax with the key's exp weighted c.
 // clip == 0: no cross-frame gather (diffusers' stock JointAttnProcessor2_0): the frame itself, once.
 // Frame shard (world > 1): this rank holds frames [rank*clip, (rank+1)*clip) of every branch; the clip's first frame and the frame
-// before this rank's first one are projected from the received hidden rows into the row blocks B + b (first) and B + nbr + b (previous) of branch b.
+// before this rank's first one are projected from the received hidden rows into the row blocks B + b (previous) and B + nbr + b (first) of branch b.
 // phase (round 6, ranks > 0 of a frame shard: the two-phase attention of csrc/attention.hip): 0 = the whole key set; 1 = only the sources this rank
 // HOLDS (the frame itself and, from its second local frame on, the previous one); 2 = only the halo sources (the clip's first frame and, for the rank's
 // first local frame, the frame before it — merged into one source of weight 2 where they are the same frame).
@@ -172,8 +172,8 @@ __global__ void sd3_index_kernel(int B, int clip, int rank, int* __restrict__ sr
     const int b = bf / clip, f = bf - b * clip;
     const int gf = rank * clip + f;                                   // frame index in the whole clip
     const int nbr = B / clip;
-    const int first = rank == 0 ? b * clip : B + b;                   // row block holding the clip's first frame (halo blocks: [first: nbr | previous: nbr])
-    const int prev = f > 0 ? bf - 1 : B + nbr + b;                    // (gf >= 1) row block of frame gf - 1
+    const int first = rank == 0 ? b * clip : B + nbr + b;             // row block holding the clip's first frame (halo blocks: [previous: nbr | first: nbr], the inbox's order)
+    const int prev = f > 0 ? bf - 1 : B + b;                          // (gf >= 1) row block of frame gf - 1
     if (phase == 1) {                       // rank > 0: gf >= 1
         cnt[bf] = f > 0 ? 2 : 1;
         if (f > 0) si[0] = prev;            // [prev, cur] / [cur]
@@ -602,18 +602,21 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             RUN(attend(1));                                                  // the keys this rank holds ++ the text keys, while the halo is on the wire
             RUN(uv_comm_kv_wait(comm, s));
             // the two halo frames of every branch from their hidden rows: to_k | to_v (+ biases) -> k RMSNorm -> the shift of each frame; rows behind the
-            // local ones, [first: nbr x N | previous: nbr x N]
+            // local ones, [previous: nbr x N | first: nbr x N]
             half_t* qh = qkv_i + rows_i * 3 * C;
             const long hrows = (long)nbr * N;
             const bool kvf = H(w->to_v) == H(w->to_k) + (long)C * Cin && ((!w->to_k_bias && !w->to_v_bias) || (w->to_k_bias && H(w->to_v_bias) == H(w->to_k_bias) + C));
-            for (int sl = 0; sl < 2; ++sl) {
-                const half_t* hx = (const half_t*)(ws_c + (sl == 0 ? o_rfirst : o_prev));
+            // (the two inbox slots [previous | first] are adjacent when a pack is a whole number of 256-byte units: one GEMM over both)
+            const bool adj = o_rfirst == o_prev + hrows * Cin * (long)sizeof(half_t);
+            for (int sl = 0; sl < (adj ? 1 : 2); ++sl) {
+                const half_t* hx = (const half_t*)(ws_c + (sl == 0 ? o_prev : o_rfirst));
                 half_t* dst = qh + (long)sl * hrows * 3 * C;
+                const long m = adj ? 2 * hrows : hrows;
                 if (kvf) {
-                    RUN(linear(hx, Cin, hrows, Cin, H(w->to_k), H(w->to_k_bias), 2 * C, dst + C, 3 * C, s));
+                    RUN(linear(hx, Cin, m, Cin, H(w->to_k), H(w->to_k_bias), 2 * C, dst + C, 3 * C, s));
                 } else {
-                    RUN(linear(hx, Cin, hrows, Cin, H(w->to_k), H(w->to_k_bias), C, dst + C, 3 * C, s));
-                    RUN(linear(hx, Cin, hrows, Cin, H(w->to_v), H(w->to_v_bias), C, dst + 2 * C, 3 * C, s));
+                    RUN(linear(hx, Cin, m, Cin, H(w->to_k), H(w->to_k_bias), C, dst + C, 3 * C, s));
+                    RUN(linear(hx, Cin, m, Cin, H(w->to_v), H(w->to_v_bias), C, dst + 2 * C, 3 * C, s));
                 }
             }
             if (w->norm_k) RUN(univst_rmsnorm_heads(qh + C, 3 * C, 2 * hrows, heads, head_dim, w->norm_k, rms_eps, s));
