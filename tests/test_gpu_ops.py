@@ -458,7 +458,8 @@ def test_attention_two_phase_local_then_halo(nat, heads, d, N, Fl, mode, pre):
 
 
 @pytest.mark.parametrize("heads,d,N,Fl,mode,pre", [(8, 40, 1024, 2, "stock", 0), (8, 40, 1024, 2, "stock", 1), (8, 40, 512, 4, "pnp", 0), (8, 80, 1024, 2, "stock", 0),
-                                                    (8, 80, 1024, 4, "pnp", 1), (8, 160, 512, 2, "stock", 1), (8, 64, 1024, 2, "stock", 0), (8, 40, 4096, 2, "pnp", 1)])
+                                                    (8, 80, 1024, 4, "pnp", 1), (8, 160, 512, 2, "stock", 1), (8, 64, 1024, 2, "stock", 0), (8, 40, 4096, 2, "pnp", 1),
+                                                    (8, 64, 1024, 2, "stock", 1), (8, 64, 2048, 2, "pnp", 1)])      # d = 64 prescaled: the pipelined kernel's two-phase forms
 def test_attention_two_phase_error_is_rounding_level(nat, heads, d, N, Fl, mode, pre):
     """The two-phase attention against an fp32 softmax over the full key set with a ROUNDING-LEVEL bound (rms 6e-4 of the rms, max 2.5e-3 of the max; the
     one-launch kernel measures 3.0e-4 / 5e-4, the split 3.3e-4) on launches of MORE blocks than the chip has CUs.  Round 6: with one kernel serving both

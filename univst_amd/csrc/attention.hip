@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256, 2) void attn_pp40_kernel(AttnParams p) {
 // per SIMD the step costs the SUM of its MFMA cycles (32 x 16 = 512) and its VALU / transcendental issue cycles (~450): the two do not
 // overlap across the two waves of a SIMD (tools/probes/coissue_probe.hip) and hardly inside one here.  What is left is less work per
 // key, not a better order.
-template <int D = 64, int QB = 4, int TAG = 0>
+template <int D = 64, int QB = 4, int TAG = 0, int TP = 0>
 __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
     static_assert(D % 16 == 0 && D % 8 == 0 && (QB == 2 || QB == 4), "whole V^T fragments, 16-byte K / V chunks");
     constexpr int NW = 4, DV16 = D / 16, NST = 3;
@@ -1114,6 +1114,10 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
     const int nsrc_eff = p.src_cnt ? p.src_cnt[bf] : p.nsrc;
     const int nseg = nsrc_eff + (p.kx ? 1 : 0);
     const int T = nsrc_eff * ntile + ntile_x;
+    if (TP && T == 0) {                   // no key source in this phase (two-phase attention, TP = 1 first phase / 2 merge phase): block-uniform, before any barrier
+        attn_empty_phase<NW * 16 * QB>(p, bf, h, qblk, D);
+        return;
+    }
     auto seg_lw = [&](int sidx) { return (sidx < nsrc_eff && p.src_logw) ? p.src_logw[bf * p.nsrc + sidx] : 0.f; };
     auto seg_nkv = [&](int sidx) { return sidx < nsrc_eff ? p.Nkv : p.Nkv_x; };
     auto seg_ntile = [&](int sidx) { return sidx < nsrc_eff ? ntile : ntile_x; };
@@ -1429,15 +1433,30 @@ __global__ __launch_bounds__(256, 2) void attn_pp64_kernel(AttnParams p) {
         float l = lsum[qb];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const float inv = 1.f / l;
+        float inv = 1.f / l, w1 = 0.f;
         const int qrow = qblk * RB + wave * 16 * QB + qb * 16 + l15;
         if (qrow >= p.Nq) continue;
         half_t* op = p.o + ((long)bf * p.Nq + qrow) * p.ldo + h * D;
+        if constexpr (TP != 0) {          // two-phase attention (see attn_body): the reference M is in log2 units here (prescaled q, reference in the accumulator)
+            const long srow = (((long)bf * p.heads + h) * p.Nq + qrow) * 2;
+            if constexpr (TP == 1) {
+                if (g == 0) *reinterpret_cast<float2*>(p.state_out + srow) = make_float2(mrun[qb], l);
+            } else {
+                const float2 st = *reinterpret_cast<const float2*>(p.state_in + srow);
+                attn_merge_coef(st.x, st.y, mrun[qb], l, w1, inv);
+            }
+        }
 #pragma unroll
         for (int dv = 0; dv < DV16; ++dv) {
             h4 ov;
+            if constexpr (TP == 2) {
+                const h4 o1 = *reinterpret_cast<const h4*>(op + dv * 16 + g * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)fmaf((float)o1[r], w1, o[dv][qb][r] * inv);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (half_t)(o[dv][qb][r] * inv);
+            }
             *reinterpret_cast<h4*>(op + dv * 16 + g * 4) = ov;
         }
     }
@@ -1637,6 +1656,15 @@ int launch_attn_tp(const AttnParams& p, hipStream_t stream) {
         if (p.q_prescaled && p.Nq >= 2048) {
             const int nqb4 = (p.Nq + 255) / 256;
             hipLaunchKernelGGL((attn_pp40_kernel<true, 0, 1, true, true, TP>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
+            UV_LAUNCH_CHECK();
+            return UV_OK;
+        }
+    }
+    if constexpr (DPAD == 64 && DV16 == 4) {      // head_dim 64 (the SD3 joint attention of ranks > 0): the pipelined kernel, as launch_attn picks it
+        static const int pp64 = getenv("UNIVST_ATTN_PP64") ? atoi(getenv("UNIVST_ATTN_PP64")) : 2;
+        if (pp64 && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && p.kx && p.Nq >= 192))) {
+            const int nqb4 = (p.Nq + 255) / 256;
+            hipLaunchKernelGGL((attn_pp64_kernel<64, 4, 0, TP>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
             return UV_OK;
         }
