@@ -711,7 +711,8 @@ def test_sd3_emulated_communicator_rank(nat, rank, world):
         torch.cuda.synchronize()
         assert torch.isfinite(v.float()).all()
     assert _native.load().univst_comm_status(comm.ptr) == 0
-    assert comm.wire_us() >= 2 * 3 * (2.0 + 2.0)          # 2 forwards x 3 attention calls (2 layers, one dual) x (exchange + barrier) x latency
+    # 2 forwards x 3 attention calls (2 layers, one dual): a barrier each, and on ranks > 0 two incoming packs each (rank 0 receives nothing)
+    assert comm.wire_us() >= 2 * 3 * 2.0 * (3 if rank > 0 else 1)
     comm.close()
 
 

@@ -224,7 +224,55 @@ static int comm_kv_post(univst_comm* c, int64_t o_send, int64_t o_first, int64_t
     UV_LAUNCH_CHECK();
     return UV_OK;
 }
-static int comm_kv_wait(univst_comm* c, hipStream_t s) {          // for the exchange the last comm_kv_post opened
+// The same exchange with its two packs posted SEPARATELY — different sizes, different moments (csrc/sd3.hip: the previous frame travels as hidden rows
+// at the start of the layer, the clip's first frame as finished K | V once rank 0 has projected, normalised and shifted it): comm_kv_begin opens the
+// exchange (one epoch for both packs), comm_kv_post_halo / comm_kv_post_first each multicast their pack and raise their own flag.  comm_kv_wait is common.
+static int comm_kv_begin(univst_comm* c) {
+    int rc = comm_check(c);
+    if (rc) return rc;
+    ++c->kv_epoch;
+    return UV_OK;
+}
+static int comm_kv_post_part(univst_comm* c, int which, int64_t o_src, int64_t o_dst, int64_t nbytes, hipStream_t x) {       // which: 0 = halo (to rank + 1), 1 = first frame (rank 0 to all)
+    UV_REQUIRE(nbytes % 16 == 0 && nbytes > 0, "kv_exchange: pack size must be a positive multiple of 16 bytes");
+    const unsigned epoch = c->kv_epoch;
+    const int par = epoch & 1;
+    auto flag = [&](int r) { return reinterpret_cast<unsigned*>(c->peer[r] + UV_OFF_FLAGS) + 32 + par * 2 + which; };
+    if (c->emulated) {             // the transfer INTO this rank, on the stream its own post runs on (packs on one link serialise there, as on rank 1's link)
+        if (c->rank == 0) return UV_OK;
+        const double us = c->emu_lat_us + (double)nbytes / (c->emu_gbps * 1e3);
+        c->emu_wire_us += us;
+        int rc = uv_launch_delay_us(us, x);
+        if (rc) return rc;
+        Flags fe;
+        fe.n = 1;
+        fe.f[0] = flag(c->rank);
+        hipLaunchKernelGGL(comm_raise_kernel, dim3(1), dim3(64), 0, x, fe, epoch);
+        UV_LAUNCH_CHECK();
+        return UV_OK;
+    }
+    const long nvec = nbytes / 16;
+    const unsigned grid = (unsigned)((nvec + 256 * 8 - 1) / (256 * 8) < 1024 ? (nvec + 256 * 8 - 1) / (256 * 8) : 1024);
+    Dsts d;
+    Flags fl;
+    d.n = fl.n = 0;
+    if (which == 0) {
+        if (c->rank >= c->world - 1) return UV_OK;
+        d.d[d.n++] = reinterpret_cast<uint4*>(c->peer[c->rank + 1] + UV_OFF_WS + o_dst);
+        fl.f[fl.n++] = flag(c->rank + 1);
+    } else {
+        if (c->rank != 0) return UV_OK;
+        for (int r = 1; r < c->world; ++r) {
+            d.d[d.n++] = reinterpret_cast<uint4*>(c->peer[r] + UV_OFF_WS + o_dst);
+            fl.f[fl.n++] = flag(r);
+        }
+    }
+    hipLaunchKernelGGL(comm_multicast_kernel, dim3(grid), dim3(256), 0, x, reinterpret_cast<const uint4*>(c->mine + UV_OFF_WS + o_src), d, nvec);
+    hipLaunchKernelGGL(comm_raise_kernel, dim3(1), dim3(64), 0, x, fl, epoch);
+    UV_LAUNCH_CHECK();
+    return UV_OK;
+}
+static int comm_kv_wait(univst_comm* c, hipStream_t s) {          // for the exchange the last comm_kv_post / comm_kv_begin opened
     if (c->rank == 0) return UV_OK;
     const unsigned epoch = c->kv_epoch;
     const int par = epoch & 1;
@@ -379,6 +427,18 @@ int uv_comm_kv_post(univst_comm* c, long o_send, long o_first, long o_prev, long
     UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
     return comm_kv_post(c, o_send, o_first, o_prev, o_rfirst, nbytes, x);
 }
+int uv_comm_kv_begin(univst_comm* c) {
+    UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
+    return comm_kv_begin(c);
+}
+int uv_comm_kv_post_halo(univst_comm* c, long o_send, long o_prev, long nbytes, hipStream_t x) {
+    UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
+    return comm_kv_post_part(c, 0, o_send, o_prev, nbytes, x);
+}
+int uv_comm_kv_post_first(univst_comm* c, long o_first, long o_rfirst, long nbytes, hipStream_t x) {
+    UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
+    return comm_kv_post_part(c, 1, o_first, o_rfirst, nbytes, x);
+}
 int uv_comm_kv_wait(univst_comm* c, hipStream_t s) {
     UV_REQUIRE(c && c->connected, "kv_exchange: communicator not connected");
     return comm_kv_wait(c, s);
@@ -426,6 +486,7 @@ int uv_comm_barrier(univst_comm* c, hipStream_t s) {             // (the first 6
 char* uv_comm_ws(univst_comm* c) { return c->mine + UV_OFF_WS; }
 long uv_comm_ws_bytes(const univst_comm* c) { return c->ws_bytes; }
 int uv_comm_rank(const univst_comm* c) { return c->rank; }
+bool uv_comm_emulated(const univst_comm* c) { return c->emulated; }
 int uv_comm_world(const univst_comm* c) { return c->world; }
 void uv_comm_bind_stream(univst_comm* c, hipStream_t s) { c->stream = s; }
 unsigned uv_comm_kv_parity(const univst_comm* c) { return (c->kv_epoch + 1) & 1; }

@@ -506,36 +506,39 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             const bool bf = (!qb && !kb && !vb) || (qb && H(kb) == H(qb) + C && H(vb) == H(kb) + C);
             return wf && bf;
         };
-        // ---- frame shard, first half of the exchange (round 6), before anything else of the layer: the HIDDEN rows (this op's input: the adaLN-modulated
-        // tokens every projection reads) of this rank's last frame of every branch -> rank + 1, of the clip's first frame (rank 0) -> every rank, on the
-        // communicator's forked stream.  Pack [branch][N][Cin] — half the K | V pack of rounds 3-5 — in the communicator's workspace: 64 KiB of
-        // all-reduce scratch, then send | first | inbox[parity][previous, first].  The RECEIVER projects the two halo frames to K | V, applies the k
-        // RMSNorm and (inside the window) the AdaIN shift itself: all per frame (pnp_utils.py:183-194).  The transfer runs beside this rank's own
-        // projections and the attention over the keys it holds.
-        long o_prev = 0, o_rfirst = 0;
+        // ---- frame shard (round 6): the exchange in two packs of different kinds, both on the communicator's forked stream.
+        //   previous frame (this rank's last frame of every branch -> rank + 1): its HIDDEN rows — this op's input, the adaLN-modulated tokens every
+        //     projection reads — [branch][N][Cin], half a K | V pack, posted before anything else of the layer; the RECEIVER projects them to K | V,
+        //     applies the k RMSNorm and (inside the window) the per-frame AdaIN shift itself (pnp_utils.py:183-194);
+        //   the clip's first frame (rank 0 -> every rank): its finished K | V [branch][N][2C], posted by rank 0 once it has projected, normalised and
+        //     shifted its own rows — every rank needs the same rows, so nobody projects them twice, and each link from rank 0 carries one such pack.
+        // Rank 1's one link from rank 0 carries both (hidden rows first); with 64 GB/s links and the config-5 shape both land before the local phase of the
+        // attention ends on every rank.  Workspace: 64 KiB of all-reduce scratch, then send | first | inbox[parity][previous, first], slots of the larger pack.
+        long o_prev = 0, o_rfirst = 0, o_first = 0;
         char* ws_c = sharded ? uv_comm_ws(comm) : nullptr;
         hipStream_t xs = s;
+        const long bytes_h = (long)nbr * N * Cin * (long)sizeof(half_t), bytes_kv = (long)nbr * N * 2 * C * (long)sizeof(half_t);
+        const bool emu = sharded && uv_comm_emulated(comm);
         if (sharded) {
-            const long pack = (((long)nbr * N * Cin * (long)sizeof(half_t)) + 255) & ~255L;
-            UV_REQUIRE(65536 + 6 * pack <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
-                       "6 hidden-row packs of %ld bytes", uv_comm_ws_bytes(comm), pack);
-            const long o_send = 65536, o_first = 65536 + pack;
+            const long slot = (((bytes_h > bytes_kv ? bytes_h : bytes_kv)) + 255) & ~255L;
+            UV_REQUIRE(65536 + 6 * slot <= uv_comm_ws_bytes(comm), "sd3_joint_attention: the communicator's workspace (%ld bytes) is smaller than 64 KiB + "
+                       "6 packs of %ld bytes", uv_comm_ws_bytes(comm), slot);
+            const long o_send = 65536;
+            o_first = 65536 + slot;
             const unsigned par = uv_comm_kv_parity(comm);
-            o_prev = 65536 + (2 + 2 * par) * pack;
-            o_rfirst = o_prev + pack;
-            const long cpn = (long)N * (Cin / 8);
-            const unsigned cgrid = (unsigned)((cpn + 255) / 256);
-            for (int b = 0; b < nbr; ++b) {
-                if (rank < world - 1)
+            o_prev = 65536 + (2 + 2 * par) * slot;
+            o_rfirst = o_prev + slot;
+            RUN(uv_comm_kv_begin(comm));
+            if (rank < world - 1) {
+                const long cpn = (long)N * (Cin / 8);
+                const unsigned cgrid = (unsigned)((cpn + 255) / 256);
+                for (int b = 0; b < nbr; ++b)
                     hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, x + ((long)(b * clip_length + clip_length - 1) * N) * Cin, (long)Cin,
                                        (half_t*)(ws_c + o_send) + (long)b * N * Cin, (long)Cin, (long)N, Cin / 8);
-                if (rank == 0)
-                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, x + ((long)b * clip_length * N) * Cin, (long)Cin,
-                                       (half_t*)(ws_c + o_first) + (long)b * N * Cin, (long)Cin, (long)N, Cin / 8);
+                UV_LAUNCH_CHECK();
             }
-            UV_LAUNCH_CHECK();
-            if (rank < world - 1) RUN(uv_comm_fork(comm, s, &xs));       // (the last rank posts nothing)
-            RUN(uv_comm_kv_post(comm, o_send, o_first, o_prev, o_rfirst, (long)nbr * N * Cin * (long)sizeof(half_t), xs));
+            if (rank < world - 1 || emu) RUN(uv_comm_fork(comm, s, &xs));
+            RUN(uv_comm_kv_post_halo(comm, o_send, o_prev, bytes_h, xs));
         }
         if (fused3(w->to_q, w->to_k, w->to_v, w->to_q_bias, w->to_k_bias, w->to_v_bias)) {
             RUN(linear(x, Cin, rows_i, Cin, H(w->to_q), H(w->to_q_bias), 3 * C, qkv_i, 3 * C, s));
@@ -553,6 +556,18 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
         else if (w->norm_k) RUN(univst_rmsnorm_heads(qkv_i + C, 3 * C, rows_i, heads, head_dim, w->norm_k, rms_eps, s));
         if (shift) {          // pnp_utils.py:183-194 (alpha 0.8, gamma 2.0); window test + beta come from the caller, evaluated in double
             RUN(univst_sd3_adain_shift(qkv_i, 3 * C, Fb, N, C, heads, 0.8f, beta, 2.0f, st, s));
+        }
+        if (sharded && (rank == 0 || emu)) {          // the clip's first frame: finished K | V rows of every branch -> every rank
+            const long cpn = (long)N * (2 * C / 8);
+            const unsigned cgrid = (unsigned)((cpn + 255) / 256);
+            if (rank == 0) {
+                for (int b = 0; b < nbr; ++b)
+                    hipLaunchKernelGGL(sd3_copy2d_kernel, dim3(cgrid), dim3(256), 0, s, qkv_i + ((long)b * clip_length * N) * 3 * C + C, (long)3 * C,
+                                       (half_t*)(ws_c + o_first) + (long)b * N * 2 * C, (long)2 * C, (long)N, 2 * C / 8);
+                UV_LAUNCH_CHECK();
+            }
+            RUN(uv_comm_fork(comm, s, &xs));
+            RUN(uv_comm_kv_post_first(comm, o_first, o_rfirst, bytes_kv, xs));
         }
         if (enc) {
             const half_t* e = H(enc);
@@ -601,28 +616,27 @@ int univst_sd3_joint_attention(const univst_sd3_attn_weights* w, const void* hid
             UV_LAUNCH_CHECK();
             RUN(attend(1));                                                  // the keys this rank holds ++ the text keys, while the halo is on the wire
             RUN(uv_comm_kv_wait(comm, s));
-            // the two halo frames of every branch from their hidden rows: to_k | to_v (+ biases) -> k RMSNorm -> the shift of each frame; rows behind the
-            // local ones, [previous: nbr x N | first: nbr x N]
+            // the halo frames, rows behind the local ones [previous: nbr x N | first: nbr x N]: the previous frame from its hidden rows (to_k | to_v +
+            // biases -> k RMSNorm -> its shift), the clip's first frame as the K | V rows rank 0 finished
             half_t* qh = qkv_i + rows_i * 3 * C;
             const long hrows = (long)nbr * N;
             const bool kvf = H(w->to_v) == H(w->to_k) + (long)C * Cin && ((!w->to_k_bias && !w->to_v_bias) || (w->to_k_bias && H(w->to_v_bias) == H(w->to_k_bias) + C));
-            // (the two inbox slots [previous | first] are adjacent when a pack is a whole number of 256-byte units: one GEMM over both)
-            const bool adj = o_rfirst == o_prev + hrows * Cin * (long)sizeof(half_t);
-            for (int sl = 0; sl < (adj ? 1 : 2); ++sl) {
-                const half_t* hx = (const half_t*)(ws_c + (sl == 0 ? o_prev : o_rfirst));
-                half_t* dst = qh + (long)sl * hrows * 3 * C;
-                const long m = adj ? 2 * hrows : hrows;
-                if (kvf) {
-                    RUN(linear(hx, Cin, m, Cin, H(w->to_k), H(w->to_k_bias), 2 * C, dst + C, 3 * C, s));
-                } else {
-                    RUN(linear(hx, Cin, m, Cin, H(w->to_k), H(w->to_k_bias), C, dst + C, 3 * C, s));
-                    RUN(linear(hx, Cin, m, Cin, H(w->to_v), H(w->to_v_bias), C, dst + 2 * C, 3 * C, s));
-                }
+            const half_t* hx = (const half_t*)(ws_c + o_prev);
+            if (kvf) {
+                RUN(linear(hx, Cin, hrows, Cin, H(w->to_k), H(w->to_k_bias), 2 * C, qh + C, 3 * C, s));
+            } else {
+                RUN(linear(hx, Cin, hrows, Cin, H(w->to_k), H(w->to_k_bias), C, qh + C, 3 * C, s));
+                RUN(linear(hx, Cin, hrows, Cin, H(w->to_v), H(w->to_v_bias), C, qh + 2 * C, 3 * C, s));
             }
-            if (w->norm_k) RUN(univst_rmsnorm_heads(qh + C, 3 * C, 2 * hrows, heads, head_dim, w->norm_k, rms_eps, s));
-            if (shift) {          // a halo frame of the three branches is the shift kernel's [3][F = 1][N]; its q columns are never projected and never read (the
-                                  // kernel mixes them element-wise, statistics come from k / v only)
-                for (int sl = 0; sl < 2; ++sl) RUN(univst_sd3_adain_shift(qh + (long)sl * hrows * 3 * C, 3 * C, 1, N, C, heads, 0.8f, beta, 2.0f, st, s));
+            if (w->norm_k) RUN(univst_rmsnorm_heads(qh + C, 3 * C, hrows, heads, head_dim, w->norm_k, rms_eps, s));
+            if (shift)            // the previous frame of the three branches is the shift kernel's [3][F = 1][N]; its q columns are never projected and never
+                                  // read (the kernel mixes them element-wise, statistics come from k / v only)
+                RUN(univst_sd3_adain_shift(qh, 3 * C, 1, N, C, heads, 0.8f, beta, 2.0f, st, s));
+            {
+                const long cpn = hrows * (2 * C / 8);
+                hipLaunchKernelGGL(sd3_copy2d_kernel, dim3((unsigned)((cpn + 255) / 256)), dim3(256), 0, s, (const half_t*)(ws_c + o_rfirst), (long)2 * C,
+                                   qh + hrows * 3 * C + C, (long)3 * C, hrows, 2 * C / 8);
+                UV_LAUNCH_CHECK();
             }
             index(2);
             UV_LAUNCH_CHECK();

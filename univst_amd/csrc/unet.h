@@ -17,6 +17,9 @@ int uv_comm_poll(univst_comm* c);
 int uv_comm_allreduce(univst_comm* c, float* buf, int n, hipStream_t s);
 int uv_comm_kv_exchange(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t s);
 int uv_comm_kv_post(univst_comm* c, long o_send, long o_first, long o_prev, long o_rfirst, long nbytes, hipStream_t x);
+int uv_comm_kv_begin(univst_comm* c);
+int uv_comm_kv_post_halo(univst_comm* c, long o_send, long o_prev, long nbytes, hipStream_t x);
+int uv_comm_kv_post_first(univst_comm* c, long o_first, long o_rfirst, long nbytes, hipStream_t x);
 int uv_comm_kv_wait(univst_comm* c, hipStream_t s);
 int uv_comm_fork(univst_comm* c, hipStream_t s, hipStream_t* x);
 int uv_comm_join(univst_comm* c, hipStream_t s);
@@ -26,6 +29,7 @@ int uv_comm_barrier(univst_comm* c, hipStream_t s);
 char* uv_comm_ws(univst_comm* c);
 long uv_comm_ws_bytes(const univst_comm* c);
 int uv_comm_rank(const univst_comm* c);
+bool uv_comm_emulated(const univst_comm* c);
 int uv_comm_world(const univst_comm* c);
 
 struct WTensor {
