@@ -1662,7 +1662,8 @@ int launch_attn_tp(const AttnParams& p, hipStream_t stream) {
     }
     if constexpr (DPAD == 64 && DV16 == 4) {      // head_dim 64 (the SD3 joint attention of ranks > 0): the pipelined kernel, as launch_attn picks it
         static const int pp64 = getenv("UNIVST_ATTN_PP64") ? atoi(getenv("UNIVST_ATTN_PP64")) : 2;
-        if (pp64 && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && p.kx && p.Nq >= 192))) {
+        // (the text queries of a joint attention — 333 rows — take it too, in the merge phase even without the text-key segment)
+        if (pp64 && p.q_prescaled && (p.Nq >= 1024 || (pp64 == 2 && (p.kx || TP == 2) && p.Nq >= 192))) {
             const int nqb4 = (p.Nq + 255) / 256;
             hipLaunchKernelGGL((attn_pp64_kernel<64, 4, 0, TP>), dim3(nqb4 * p.heads * p.BF), dim3(256), 0, stream, p);
             UV_LAUNCH_CHECK();
