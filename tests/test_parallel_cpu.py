@@ -149,6 +149,123 @@ def test_frame_shard_schedule_gloo_world2():
         assert msg == "ok", f"rank {r}: {msg}"
 
 
+def _sd3_worker(rank, world, port, out):
+    """the SD3 / SD3.5 exchange schedule of csrc/sd3.hip (round 6) restated with torch ops and the gloo communicator, against the UNSHARDED oracle
+    (oracle/sd3_ref.joint_attention = backbones/video_diffusion_sd3/pnp_utils.py:17-271): the previous frame travels as the layer's hidden rows (the
+    receiver projects, RMS-normalises and shifts it), the clip's first frame as the K | V rows rank 0 finished, and the joint attention runs in two
+    phases — keys the rank holds ++ the text keys, then the halo frames — for the image AND the text queries."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import sd3_ref
+        from univst_amd.parallel import Sd3FrameShard, TorchDistComm
+        comm = TorchDistComm()
+        B, Fr, N, Nt, C, heads = 3, 4, 6, 3, 16, 2
+        d = C // heads
+        sh = Sd3FrameShard(rank, world, Fr, comm=comm)
+        g = torch.Generator().manual_seed(5)
+        rn = lambda *s_: torch.randn(*s_, generator=g)
+        P = {}
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            P[n + ".weight"], P[n + ".bias"] = rn(C, C) / C ** 0.5, rn(C) * 0.1
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            P[n + ".weight"] = 1.0 + 0.2 * rn(d)
+        hidden, enc = rn(B * Fr, N, C), rn(B * Fr, Nt, C)
+        lin = lambda x, n: F.linear(x, P[n + ".weight"], P[n + ".bias"])
+        sp = lambda t: t.view(t.shape[0], -1, heads, d).transpose(1, 2)                     # [(b f), heads, tokens, d]
+        rms = lambda x, n: sd3_ref._rms(x, P[n + ".weight"], 1e-6)
+
+        def shifted(q, k, v, idx):              # pnp_utils.py:183-194 on [(3 c), heads, N, d]: per frame, so it applies to any subset of whole frames
+            c = q.shape[0] // 3
+            if not (idx >= 0 and idx <= 0.6 * 50):
+                return q, k, v
+            beta = (0.9 - 0.1) / (0 - 0.6 * 50) * (idx - 0.6 * 50) + 0.1
+            q, k, v = q.clone(), k.clone(), v.clone()
+            q[2 * c:] = 2.0 * (0.8 * q[:c] + 0.2 * q[2 * c:])
+            k[2 * c:] = beta * sd3_ref.attention_adain(k[2 * c:], k[c:2 * c]) + (1 - beta) * k[c:2 * c]
+            v[2 * c:] = beta * sd3_ref.attention_adain(v[2 * c:], v[c:2 * c]) + (1 - beta) * v[c:2 * c]
+            return q, k, v
+
+        def phase(qf, ks, vs):                  # qf [3, heads, nq, d]; key lists of [3, heads, n, d]
+            if not ks:
+                return None
+            kk, vv = torch.cat(ks, 2), torch.cat(vs, 2)
+            sc = qf @ kk.transpose(2, 3) / d ** 0.5
+            m = sc.amax(-1)
+            pr = torch.exp(sc - m[..., None])
+            l = pr.sum(-1)
+            return m, l, (pr / l[..., None]) @ vv
+
+        def merge(s1, s2):
+            if s2 is None:
+                return s1[2]
+            m = torch.maximum(s1[0], s2[0])
+            a1, a2 = s1[1] * torch.exp(s1[0] - m), s2[1] * torch.exp(s2[0] - m)
+            return s1[2] * (a1 / (a1 + a2))[..., None] + s2[2] * (a2 / (a1 + a2))[..., None]
+
+        for idx in (12, 45):
+            want_i, want_t = sd3_ref.joint_attention(P, heads, hidden, enc, idx=idx, shift=True, clip_length=Fr)
+            loc5 = lambda t: t.view(B, Fr, *t.shape[1:])[:, sh.f0:sh.f0 + sh.local]
+            hl, el = loc5(hidden), loc5(enc)                                               # [3, local, tokens, C]
+            flat = lambda t: t.reshape(B * sh.local, *t.shape[2:])
+            q, k, v = sp(lin(flat(hl), "to_q")), sp(lin(flat(hl), "to_k")), sp(lin(flat(hl), "to_v"))
+            q, k = rms(q, "norm_q"), rms(k, "norm_k")
+            q, k, v = shifted(q, k, v, idx)
+            eq, ek, ev = sp(lin(flat(el), "add_q_proj")), sp(lin(flat(el), "add_k_proj")), sp(lin(flat(el), "add_v_proj"))
+            eq, ek = rms(eq, "norm_added_q"), rms(ek, "norm_added_k")
+            v5 = lambda t: t.view(B, sh.local, *t.shape[1:])                               # [3, local, heads, tokens, d]
+            q5, k5, v5_, eq5, ek5, ev5 = (v5(t) for t in (q, k, v, eq, ek, ev))
+            # ---- the two packs: previous frame = hidden rows [3, N, C]; first frame = finished K | V [3, N, 2C] (rank 0's)
+            send_last = hl[:, sh.local - 1].contiguous()
+            kv_first = torch.cat([k5[:, 0].transpose(1, 2).reshape(B, N, C), v5_[:, 0].transpose(1, 2).reshape(B, N, C)], -1).contiguous()
+            recv_prev, recv_first = torch.zeros_like(send_last), torch.zeros_like(kv_first)
+            dist.broadcast(kv_first if rank == 0 else recv_first, src=0)
+            if rank < world - 1:
+                dist.send(send_last, rank + 1)
+            if rank > 0:
+                dist.recv(recv_prev, rank - 1)
+                pq, pk, pv = sp(lin(recv_prev, "to_q")), sp(lin(recv_prev, "to_k")), sp(lin(recv_prev, "to_v"))
+                pk = rms(pk, "norm_k")
+                _, pk, pv = shifted(pq, pk, pv, idx)                                       # one frame of the three branches: c = 1
+                fk, fv = sp(recv_first[..., :C]), sp(recv_first[..., C:])
+            oi, ot = [], []
+            for f in range(sh.local):
+                if rank == 0:                   # everything local; duplicates as the reference lists them ['first', f - 1 clipped, f]
+                    lk, lv = [k5[:, 0], k5[:, max(f - 1, 0)], k5[:, f]], [v5_[:, 0], v5_[:, max(f - 1, 0)], v5_[:, f]]
+                    hk, hv = [], []
+                else:
+                    lk, lv = ([k5[:, f - 1]] if f > 0 else []) + [k5[:, f]], ([v5_[:, f - 1]] if f > 0 else []) + [v5_[:, f]]
+                    hk, hv = [fk] + ([pk] if f == 0 else []), [fv] + ([pv] if f == 0 else [])
+                lk, lv = lk + [ek5[:, f]], lv + [ev5[:, f]]                                # the text keys ride in the first phase
+                for qq, dst in ((q5[:, f], oi), (eq5[:, f], ot)):
+                    o = merge(phase(qq, lk, lv), phase(qq, hk, hv))
+                    dst.append(o.transpose(1, 2).reshape(B, -1, C))
+            got_i = lin(torch.stack(oi, 1), "to_out.0")
+            got_t = lin(torch.stack(ot, 1), "to_add_out")
+            ei, et = (got_i - loc5(want_i)).abs().max(), (got_t - loc5(want_t)).abs().max()
+            assert ei < 2e-5 and et < 2e-5, (idx, float(ei), float(et))
+        out.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        out.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sd3_frame_shard_schedule_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sd3_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}: {msg}"
+
+
 def test_frame_shard_slicing():
     from univst_amd.parallel import FrameShard
     t = torch.arange(2 * 4 * 8).view(1, 2, 8, 2, 2)
