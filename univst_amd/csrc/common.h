@@ -97,17 +97,27 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // 5.7e-7; |gelu error| <= 2e-6 absolute, three orders below fp16 resolution of the product that is stored).  Every operation is a
 // v_pk_fma_f32 / v_pk_mul_f32 on the pair plus one v_med3_f32 per value: 10 issue slots per value (ISA-counted).
 typedef float f2 __attribute__((ext_vector_type(2)));
+// UV_GELU_DEG9 (A/B build, round 6: -DUV_GELU_DEG9): degree 9 with the clamp at 4.5 (|gelu error| <= 8.5e-5 absolute) instead of degree 12 at 5.0 (2e-6)
+#ifdef UV_GELU_DEG9
+#define UV_GELU_N 10
+#define UV_GELU_CLAMP 4.5f
+#define UV_GELU_S 0.09876543209876543f
+#define UV_GELU_COEF {3.138136918e-01f, -1.543877219e-01f, 1.092108398e-01f, -8.021842318e-02f, 5.810019385e-02f, -3.804188117e-02f, 1.858792292e-02f, -1.050309624e-02f, 1.033601781e-02f, -4.680031871e-03f}
+#else
+#define UV_GELU_N 13
+#define UV_GELU_CLAMP 5.f
+#define UV_GELU_S 0.08f
+#define UV_GELU_COEF {2.827276369e-01f, -1.405918177e-01f, 1.030358595e-01f, -8.090256480e-02f, 6.295351729e-02f, -4.642625655e-02f, 3.247217962e-02f, -2.261424982e-02f, 1.353305501e-02f, -5.053833458e-03f, 2.749192302e-03f, -3.353461957e-03f, 1.470752778e-03f}
+#endif
 __device__ __forceinline__ f2 geglu_erf2(f2 x, f2 g) {
     f2 gc;
-    gc.x = __builtin_amdgcn_fmed3f(g.x, -5.f, 5.f);
-    gc.y = __builtin_amdgcn_fmed3f(g.y, -5.f, 5.f);
-    const f2 s = __builtin_elementwise_fma(gc * 0.08f, gc, f2{-1.f, -1.f});
-    constexpr float c[13] = {2.827276369e-01f, -1.405918177e-01f, 1.030358595e-01f, -8.090256480e-02f, 6.295351729e-02f, -4.642625655e-02f,
-                             3.247217962e-02f, -2.261424982e-02f, 1.353305501e-02f, -5.053833458e-03f, 2.749192302e-03f, -3.353461957e-03f,
-                             1.470752778e-03f};
-    f2 p = f2{c[12], c[12]};
+    gc.x = __builtin_amdgcn_fmed3f(g.x, -UV_GELU_CLAMP, UV_GELU_CLAMP);
+    gc.y = __builtin_amdgcn_fmed3f(g.y, -UV_GELU_CLAMP, UV_GELU_CLAMP);
+    const f2 s = __builtin_elementwise_fma(gc * UV_GELU_S, gc, f2{-1.f, -1.f});
+    constexpr float c[UV_GELU_N] = UV_GELU_COEF;
+    f2 p = f2{c[UV_GELU_N - 1], c[UV_GELU_N - 1]};
 #pragma unroll
-    for (int i = 11; i >= 0; --i) p = __builtin_elementwise_fma(p, s, f2{c[i], c[i]});
+    for (int i = UV_GELU_N - 2; i >= 0; --i) p = __builtin_elementwise_fma(p, s, f2{c[i], c[i]});
     const f2 S = gc * p;
     const f2 t = (x * 0.5f) * g;
     return __builtin_elementwise_fma(t, S, t);
@@ -117,18 +127,16 @@ __device__ __forceinline__ f2 geglu_erf2(f2 x, f2 g) {
 // producer, and hipcc (at 245-251 VGPRs) schedules the chains of a block one after the other, padding every link of the second with an s_nop
 __device__ __forceinline__ void geglu_erf2x2(f2 xa, f2 ga, f2 xb, f2 gb, f2& ya, f2& yb) {
     f2 ca, cb;
-    ca.x = __builtin_amdgcn_fmed3f(ga.x, -5.f, 5.f);
-    ca.y = __builtin_amdgcn_fmed3f(ga.y, -5.f, 5.f);
-    cb.x = __builtin_amdgcn_fmed3f(gb.x, -5.f, 5.f);
-    cb.y = __builtin_amdgcn_fmed3f(gb.y, -5.f, 5.f);
-    const f2 sa = __builtin_elementwise_fma(ca * 0.08f, ca, f2{-1.f, -1.f});
-    const f2 sb = __builtin_elementwise_fma(cb * 0.08f, cb, f2{-1.f, -1.f});
-    constexpr float c[13] = {2.827276369e-01f, -1.405918177e-01f, 1.030358595e-01f, -8.090256480e-02f, 6.295351729e-02f, -4.642625655e-02f,
-                             3.247217962e-02f, -2.261424982e-02f, 1.353305501e-02f, -5.053833458e-03f, 2.749192302e-03f, -3.353461957e-03f,
-                             1.470752778e-03f};
-    f2 pa = f2{c[12], c[12]}, pb = f2{c[12], c[12]};
+    ca.x = __builtin_amdgcn_fmed3f(ga.x, -UV_GELU_CLAMP, UV_GELU_CLAMP);
+    ca.y = __builtin_amdgcn_fmed3f(ga.y, -UV_GELU_CLAMP, UV_GELU_CLAMP);
+    cb.x = __builtin_amdgcn_fmed3f(gb.x, -UV_GELU_CLAMP, UV_GELU_CLAMP);
+    cb.y = __builtin_amdgcn_fmed3f(gb.y, -UV_GELU_CLAMP, UV_GELU_CLAMP);
+    const f2 sa = __builtin_elementwise_fma(ca * UV_GELU_S, ca, f2{-1.f, -1.f});
+    const f2 sb = __builtin_elementwise_fma(cb * UV_GELU_S, cb, f2{-1.f, -1.f});
+    constexpr float c[UV_GELU_N] = UV_GELU_COEF;
+    f2 pa = f2{c[UV_GELU_N - 1], c[UV_GELU_N - 1]}, pb = f2{c[UV_GELU_N - 1], c[UV_GELU_N - 1]};
 #pragma unroll
-    for (int i = 11; i >= 0; --i) {
+    for (int i = UV_GELU_N - 2; i >= 0; --i) {
         pa = __builtin_elementwise_fma(pa, sa, f2{c[i], c[i]});
         pb = __builtin_elementwise_fma(pb, sb, f2{c[i], c[i]});
         __builtin_amdgcn_sched_barrier(0);              // keep the two chains alternating
